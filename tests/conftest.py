@@ -1,0 +1,37 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "ct-clip-ut_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+
+
+def load_golden(name):
+    """Load tests/golden/<name>.npz as {key: torch tensor}."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    out = {}
+    for k in z.files:
+        a = z[k]
+        out[k] = torch.from_numpy(a) if a.dtype.kind in "fiub" else a
+    return out
+
+
+def sub(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
