@@ -1,0 +1,524 @@
+// Fused attention for gfx950: softmax(q k^T * scale + bias[h,i,j] + mask[seq,j]) v, forward and backward.
+//
+// Serves the three attention shapes of the CT-CLIP step:
+//   CT-ViT spatial  (reference src/utils/attention.py:155-180): n = 576, d_head = 32, bias [8,576,576]
+//   CT-ViT temporal (same code, no bias):                       n = 24,  d_head = 32
+//   BERT self-attention (transformers BertSelfAttention):       n = L,   d_head = 64, additive key mask
+// The cosine-sim l2norm / q_scale / k_scale / `scale = 8` of attention.py:151-155 are applied to q,k
+// by ctclip_headnorm_* before this kernel, so here `scale` is 1 for CT-ViT and 1/sqrt(d) for BERT.
+//
+// Layout: q,k,v,o,do are [nseq*n, ld] bf16 row-major, head h occupying columns h*D .. h*D+D-1
+// (the 'b n (h d)' layout the projections produce, attention.py:144,180) -- heads are never split
+// into separate tensors.
+//
+// Structure (one workgroup per (row-block, head, sequence); each wave owns 32 rows):
+//   * K and V (forward, dQ pass) or Q and dO (dK/dV pass) of the whole sequence are staged once in
+//     LDS as swizzled [n][D] images that serve both ds_read_b128 row reads and ds_read_b64_tr_b16
+//     transposed reads without bank conflicts.
+//   * scores are computed "key-major" (S^T = K Q^T) in the forward/dQ passes so that a query's
+//     row statistics live in one lane (+ its lane^32 partner): softmax needs one cross-lane op.
+//   * every second product consumes the f32 accumulator of the first directly as an MFMA operand
+//     (v_cvt to bf16, no LDS round trip): O^T = V^T P^T, dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS.
+//   * the n x n probability matrix is never written; backward recomputes it from the saved
+//     log-sum-exp.  d(bias) is reduced on chip into a [heads][R] relative-position table through
+//     LDS atomics (the CT-ViT bias has only (2h-1)(2w-1) distinct values per head), or, for
+//     arbitrary biases, added to a dense [heads,n,n] buffer with global atomics.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;
+  bf16_t* o;                 // fwd out
+  float* lse;                // [nseq, H, n]
+  const float* bias;         // [H, n, n] or null
+  const float* mask;         // [nseq, n] additive or null
+  const bf16_t* dO;          // bwd
+  const bf16_t* oin;         // bwd: forward output (for delta)
+  float* delta;              // [nseq, H, n]
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;
+  float* dbias_dense;        // [H, n, n] or null
+  const uint16_t* relidx;    // [n, n] or null
+  float* dbias_table;        // [H, R] or null
+  int table_size;            // R
+  long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int nseq, n, n_pad, heads;
+  float scale;
+};
+
+template <int D>
+__device__ __forceinline__ uint32_t img_off(int row, int chunk) {
+  if (D == 32) return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+  return (uint32_t)(row * 128 + ((chunk ^ (((row >> 2) & 3) | (((row >> 1) & 1) << 2))) << 4));
+}
+
+// stage rows [0,n) of a [*, ld] matrix (columns head*D..) into a swizzled LDS image; rows n..n_pad-1 = 0
+template <int D>
+__device__ __forceinline__ void load_image(char* img, const bf16_t* __restrict__ base, long ld, int n, int n_pad,
+                                           int tid, int nthreads) {
+  constexpr int CH = D / 8;
+  for (int id = tid; id < n_pad * CH; id += nthreads) {
+    const int r = id / CH, c = id % CH;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < n) v = *(const uint4*)(base + (long)r * ld + c * 8);
+    *(uint4*)(img + img_off<D>(r, c)) = v;
+  }
+}
+
+// A/B fragment for MFMA 32x32x16: element j = M[row0 + (lane&31)][16*s + 8*(lane>>5) + j]
+template <int D>
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int row0, int s, int lane) {
+  return *(const bf16x8*)(img + img_off<D>(row0 + (lane & 31), 2 * s + (lane >> 5)));
+}
+
+// transposed fragment: element j = M[row0 + 16*s + 8*(j>>2) + 4*(lane>>5) + (j&3)][32*dt + (lane&31)]
+// (the k-order an f32 32x32 accumulator has when it is re-used as the other operand)
+template <int D>
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int s, int dt, int lane) {
+  const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3, h = g >> 1;
+  const int col = 32 * dt + 16 * (g & 1) + 4 * p;
+  const int rlo = row0 + 16 * s + 4 * h + qq;
+  const uint32_t sub = (uint32_t)((p & 1) * 8);
+  short4v lo = lds_read_tr16(img + img_off<D>(rlo, col >> 3) + sub);
+  short4v hi = lds_read_tr16(img + img_off<D>(rlo + 8, col >> 3) + sub);
+  return join_tr(lo, hi);
+}
+
+// fragment straight from global memory: element j = M[row][16*s + 8*(lane>>5) + j]
+__device__ __forceinline__ bf16x8 gfrag(const bf16_t* __restrict__ rowptr, int s, int lane, bool valid) {
+  short8v z = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (valid) z = *(const short8v*)(rowptr + 16 * s + 8 * (lane >> 5));
+  return as_bf16x8(z);
+}
+
+// registers 8s..8s+7 of an accumulator -> bf16 fragment of k-step s
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * s + j];
+  return r;
+}
+
+__device__ __forceinline__ void zero_acc(f32x16& a) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = 0.f;
+}
+
+// store one wave's [D x 32] transposed accumulator tile as rows of a [*, ld] bf16 matrix:
+// lane (r, h) owns row `row`, columns 32*dt + 8*g4 + 4*h + (0..3)
+template <int D>
+__device__ __forceinline__ void store_rows(bf16_t* __restrict__ rowptr, const f32x16 (&acc)[D / 32], float mul, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      uint2 p;
+      p.x = pack_bf16x2(acc[dt][4 * g4 + 0] * mul, acc[dt][4 * g4 + 1] * mul);
+      p.y = pack_bf16x2(acc[dt][4 * g4 + 2] * mul, acc[dt][4 * g4 + 3] * mul);
+      *(uint2*)(rowptr + 32 * dt + 8 * g4 + 4 * h) = p;
+    }
+}
+
+// scores of one 32x32 tile in "row of accumulator = key, lane = query" orientation
+// v[reg] = acc*scale + bias[head][q][key] + mask[key]; keys >= n -> -inf
+__device__ __forceinline__ void score_keymajor(f32x16& s, const AttnArgs& a, int head, int seq, int qrow_c, int key_base,
+                                               int half) {
+  const float* brow = a.bias ? a.bias + ((long)head * a.n + qrow_c) * a.n : nullptr;
+  const float* mrow = a.mask ? a.mask + (long)seq * a.n : nullptr;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int k0 = key_base + 8 * g4 + 4 * half;
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (brow) {
+      if (((a.n & 3) == 0) && k0 + 3 < a.n) {
+        const float4 t = *(const float4*)(brow + k0);
+        b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (k0 + i < a.n) b[i] = brow[k0 + i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = k0 + i;
+      float v = s[4 * g4 + i] * a.scale + b[i];
+      if (mrow && key < a.n) v += mrow[key];
+      s[4 * g4 + i] = (key < a.n) ? v : -INFINITY;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = D / 16, DT = D / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int half = lane >> 5;
+  char* kimg = smem;
+  char* vimg = smem + (size_t)a.n_pad * D * 2;
+  const long row_base = (long)seq * a.n;
+  load_image<D>(kimg, a.k + row_base * a.ldk + head * D, a.ldk, a.n, a.n_pad, tid, blockDim.x);
+  load_image<D>(vimg, a.v + row_base * a.ldv + head * D, a.ldv, a.n, a.n_pad, tid, blockDim.x);
+  __syncthreads();
+
+  const int q0 = (blockIdx.x * nwaves + wave) * 32;
+  if (q0 >= a.n) return;  // no barrier after this point
+  const int qrow = q0 + (lane & 31);
+  const bool valid = qrow < a.n;
+  const int qrow_c = valid ? qrow : a.n - 1;
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) qf[s] = gfrag(a.q + (row_base + qrow_c) * a.ldq + head * D, s, lane, valid);
+
+  float m = -INFINITY, l = 0.f;
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) zero_acc(oacc[dt]);
+
+  for (int kt = 0; kt < a.n_pad; kt += 32) {
+    f32x16 s;
+    zero_acc(s);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<D>(kimg, kt, ks, lane), qf[ks], s);
+    score_keymajor(s, a, head, seq, qrow_c, kt, half);
+    float tmax = s[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float mnew = fmaxf(m, tmax);
+    const float alpha = (m == -INFINITY) ? 0.f : __expf(m - mnew);
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float p = (mnew == -INFINITY) ? 0.f : __expf(s[i] - mnew);
+      s[i] = p;
+      psum += p;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l = l * alpha + psum;
+    m = mnew;
+    const bf16x8 p0 = acc_frag(s, 0), p1 = acc_frag(s, 1);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+      oacc[dt] = mfma32(tr_frag<D>(vimg, kt, 0, dt, lane), p0, oacc[dt]);
+      oacc[dt] = mfma32(tr_frag<D>(vimg, kt, 1, dt, lane), p1, oacc[dt]);
+    }
+  }
+  if (valid) {
+    const float inv = 1.0f / l;
+    store_rows<D>(a.o + (row_base + qrow) * a.ldo + head * D, oacc, inv, lane);
+    if (half == 0) a.lse[((long)seq * a.heads + head) * a.n + qrow] = m + __logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 1: dQ, delta = rowsum(dO * O), d(bias)
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = D / 16, DT = D / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int half = lane >> 5;
+  char* kimg = smem;
+  char* vimg = smem + (size_t)a.n_pad * D * 2;
+  float* table = (float*)(smem + (size_t)a.n_pad * D * 4);
+  const long row_base = (long)seq * a.n;
+  load_image<D>(kimg, a.k + row_base * a.ldk + head * D, a.ldk, a.n, a.n_pad, tid, blockDim.x);
+  load_image<D>(vimg, a.v + row_base * a.ldv + head * D, a.ldv, a.n, a.n_pad, tid, blockDim.x);
+  if (a.dbias_table)
+    for (int i = tid; i < a.table_size; i += blockDim.x) table[i] = 0.f;
+  __syncthreads();
+
+  const int q0 = (blockIdx.x * nwaves + wave) * 32;
+  const bool wave_active = q0 < a.n;  // inactive waves still reach the final barrier
+  if (wave_active) {
+    const int qrow = q0 + (lane & 31);
+    const bool valid = qrow < a.n;
+    const int qrow_c = valid ? qrow : a.n - 1;
+    const long stat = ((long)seq * a.heads + head) * a.n + qrow_c;
+    bf16x8 qf[KS], dof[KS];
+    float dsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      qf[s] = gfrag(a.q + (row_base + qrow_c) * a.ldq + head * D, s, lane, valid);
+      dof[s] = gfrag(a.dO + (row_base + qrow_c) * a.lddo + head * D, s, lane, valid);
+      const bf16x8 of = gfrag(a.oin + (row_base + qrow_c) * a.ldo + head * D, s, lane, valid);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dsum += (float)dof[s][j] * (float)of[j];
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (valid && half == 0) a.delta[stat] = dsum;
+    const float lse = a.lse[stat];
+
+    f32x16 dqacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) zero_acc(dqacc[dt]);
+
+    for (int kt = 0; kt < a.n_pad; kt += 32) {
+      f32x16 s, dp;
+      zero_acc(s);
+      zero_acc(dp);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        s = mfma32(row_frag<D>(kimg, kt, ks, lane), qf[ks], s);
+        dp = mfma32(row_frag<D>(vimg, kt, ks, lane), dof[ks], dp);
+      }
+      score_keymajor(s, a, head, seq, qrow_c, kt, half);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = valid ? __expf(s[i] - lse) : 0.f;  // -inf scores -> 0
+        s[i] = p * (dp[i] - dsum);                          // dS^T[key][q]
+      }
+      if (valid && (a.dbias_dense || a.dbias_table)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kt + acc_row(i, half);
+          if (key < a.n) {
+            if (a.dbias_dense) atomicAdd(a.dbias_dense + ((long)head * a.n + qrow) * a.n + key, s[i]);
+            else atomicAdd(&table[a.relidx[(long)qrow * a.n + key]], s[i]);
+          }
+        }
+      }
+      const bf16x8 d0 = acc_frag(s, 0), d1 = acc_frag(s, 1);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        dqacc[dt] = mfma32(tr_frag<D>(kimg, kt, 0, dt, lane), d0, dqacc[dt]);
+        dqacc[dt] = mfma32(tr_frag<D>(kimg, kt, 1, dt, lane), d1, dqacc[dt]);
+      }
+    }
+    if (valid) store_rows<D>(a.dq + (row_base + qrow) * a.lddq + head * D, dqacc, a.scale, lane);
+  }
+  if (a.dbias_table) {
+    __syncthreads();
+    for (int i = tid; i < a.table_size; i += blockDim.x) {
+      const float v = table[i];
+      if (v != 0.f) atomicAdd(a.dbias_table + (long)head * a.table_size + i, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 2: dK, dV (each wave owns 32 keys, sweeps all query tiles)
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = D / 16, DT = D / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int half = lane >> 5;
+  char* qimg = smem;
+  char* doimg = smem + (size_t)a.n_pad * D * 2;
+  float* lse_s = (float*)(smem + (size_t)a.n_pad * D * 4);
+  float* del_s = lse_s + a.n_pad;
+  const long row_base = (long)seq * a.n;
+  load_image<D>(qimg, a.q + row_base * a.ldq + head * D, a.ldq, a.n, a.n_pad, tid, blockDim.x);
+  load_image<D>(doimg, a.dO + row_base * a.lddo + head * D, a.lddo, a.n, a.n_pad, tid, blockDim.x);
+  const long stat_base = ((long)seq * a.heads + head) * a.n;
+  for (int i = tid; i < a.n_pad; i += blockDim.x) {
+    lse_s[i] = (i < a.n) ? a.lse[stat_base + i] : INFINITY;   // exp(v - inf) = 0 for padded queries
+    del_s[i] = (i < a.n) ? a.delta[stat_base + i] : 0.f;
+  }
+  __syncthreads();
+
+  const int key0 = (blockIdx.x * nwaves + wave) * 32;
+  if (key0 >= a.n) return;
+  const int key = key0 + (lane & 31);
+  const bool valid = key < a.n;
+  const int key_c = valid ? key : a.n - 1;
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    kf[s] = gfrag(a.k + (row_base + key_c) * a.ldk + head * D, s, lane, valid);
+    vf[s] = gfrag(a.v + (row_base + key_c) * a.ldv + head * D, s, lane, valid);
+  }
+  const float mval = (a.mask && valid) ? a.mask[(long)seq * a.n + key] : 0.f;
+  const float* bcol = a.bias ? a.bias + (long)head * a.n * a.n + key_c : nullptr;
+
+  f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    zero_acc(dkacc[dt]);
+    zero_acc(dvacc[dt]);
+  }
+  for (int qt = 0; qt < a.n_pad; qt += 32) {
+    f32x16 s, dp;
+    zero_acc(s);
+    zero_acc(dp);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s = mfma32(row_frag<D>(qimg, qt, ks, lane), kf[ks], s);     // S[q][key]
+      dp = mfma32(row_frag<D>(doimg, qt, ks, lane), vf[ks], dp);  // dP[q][key]
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int qb = qt + 8 * g4 + 4 * half;
+      const float4 l4 = *(const float4*)(lse_s + qb);
+      const float4 d4 = *(const float4*)(del_s + qb);
+      const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = qb + i;
+        float v = s[4 * g4 + i] * a.scale + mval;
+        if (bcol && q < a.n) v += bcol[(long)q * a.n];
+        const float p = valid ? __expf(v - ls[i]) : 0.f;
+        s[4 * g4 + i] = p;
+        dp[4 * g4 + i] = p * (dp[4 * g4 + i] - de[i]);
+      }
+    }
+    const bf16x8 p0 = acc_frag(s, 0), p1 = acc_frag(s, 1), d0 = acc_frag(dp, 0), d1 = acc_frag(dp, 1);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      dvacc[dt] = mfma32(tr_frag<D>(doimg, qt, 0, dt, lane), p0, dvacc[dt]);
+      dvacc[dt] = mfma32(tr_frag<D>(doimg, qt, 1, dt, lane), p1, dvacc[dt]);
+      dkacc[dt] = mfma32(tr_frag<D>(qimg, qt, 0, dt, lane), d0, dkacc[dt]);
+      dkacc[dt] = mfma32(tr_frag<D>(qimg, qt, 1, dt, lane), d1, dkacc[dt]);
+    }
+  }
+  if (valid) {
+    store_rows<D>(a.dk + (row_base + key) * a.lddk + head * D, dkacc, a.scale, lane);
+    store_rows<D>(a.dv + (row_base + key) * a.lddv + head * D, dvacc, 1.0f, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// materialise probabilities (only for callers that ask Attention.forward for them, attention.py:182)
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void attn_probs_kernel(AttnArgs a, float* __restrict__ probs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KS = D / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int head = blockIdx.y, seq = blockIdx.z;
+  const int half = lane >> 5;
+  char* kimg = smem;
+  const long row_base = (long)seq * a.n;
+  load_image<D>(kimg, a.k + row_base * a.ldk + head * D, a.ldk, a.n, a.n_pad, tid, blockDim.x);
+  __syncthreads();
+  const int q0 = (blockIdx.x * nwaves + wave) * 32;
+  if (q0 >= a.n) return;
+  const int qrow = q0 + (lane & 31);
+  const bool valid = qrow < a.n;
+  const int qrow_c = valid ? qrow : a.n - 1;
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) qf[s] = gfrag(a.q + (row_base + qrow_c) * a.ldq + head * D, s, lane, valid);
+  const float lse = a.lse[((long)seq * a.heads + head) * a.n + qrow_c];
+  float* prow = probs + (((long)seq * a.heads + head) * a.n + qrow_c) * a.n;
+  for (int kt = 0; kt < a.n_pad; kt += 32) {
+    f32x16 s;
+    zero_acc(s);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<D>(kimg, kt, ks, lane), qf[ks], s);
+    score_keymajor(s, a, head, seq, qrow_c, kt, half);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = kt + acc_row(i, half);
+      if (valid && key < a.n) prow[key] = __expf(s[i] - lse);
+    }
+  }
+}
+
+int check(const AttnArgs& a, int dhead) {
+  if (dhead != 32 && dhead != 64) return (int)hipErrorInvalidValue;
+  if (a.n <= 0 || a.nseq <= 0 || a.heads <= 0) return (int)hipErrorInvalidValue;
+  if (a.heads > 65535 || a.nseq > 65535 * 32) return (int)hipErrorInvalidValue;
+  return 0;
+}
+
+inline int waves_for(int n) {
+  const int tiles = (n + 31) / 32;
+  return tiles < 4 ? tiles : 4;  // 256-thread workgroups
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctclip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
+                    const float* mask, int nseq, int n, int heads, int dhead, long ldq, long ldk, long ldv, long ldo,
+                    float scale, void* stream) {
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
+  a.bias = bias; a.mask = mask; a.nseq = nseq; a.n = n; a.n_pad = (n + 31) / 32 * 32; a.heads = heads;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+  if (int e = check(a, dhead)) return e;
+  const int nw = waves_for(n);
+  dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
+  const size_t lds = (size_t)a.n_pad * dhead * 4;
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  if (dhead == 32) {
+    if (lds > 65536) hipFuncSetAttribute((const void*)attn_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, block, lds, (hipStream_t)stream, a);
+  } else {
+    if (lds > 65536) hipFuncSetAttribute((const void*)attn_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, lds, (hipStream_t)stream, a);
+  }
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
+                    float* delta, void* dq, void* dk, void* dv, const float* bias, const float* mask,
+                    float* dbias_dense, const uint16_t* relidx, float* dbias_table, int table_size, int nseq, int n,
+                    int heads, int dhead, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk,
+                    long lddv, float scale, void* stream) {
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.oin = (const bf16_t*)o;
+  a.dO = (const bf16_t*)dO; a.lse = (float*)lse; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk;
+  a.dv = (bf16_t*)dv; a.bias = bias; a.mask = mask; a.dbias_dense = dbias_dense; a.relidx = relidx;
+  a.dbias_table = (relidx && !dbias_dense) ? dbias_table : nullptr; a.table_size = table_size;
+  a.nseq = nseq; a.n = n; a.n_pad = (n + 31) / 32 * 32; a.heads = heads;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.scale = scale;
+  if (int e = check(a, dhead)) return e;
+  const int nw = waves_for(n);
+  dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
+  const size_t lds1 = (size_t)a.n_pad * dhead * 4 + (a.dbias_table ? (size_t)table_size * 4 : 0);
+  const size_t lds2 = (size_t)a.n_pad * dhead * 4 + (size_t)a.n_pad * 8;
+  if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  if (dhead == 32) {
+    if (lds1 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (lds2 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, lds1, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid, block, lds2, st, a);
+  } else {
+    if (lds1 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (lds2 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, lds1, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, lds2, st, a);
+  }
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_attn_probs(const void* q, const void* k, const float* lse, const float* bias, const float* mask,
+                      float* probs, int nseq, int n, int heads, int dhead, long ldq, long ldk, float scale,
+                      void* stream) {
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.lse = (float*)lse; a.bias = bias; a.mask = mask;
+  a.nseq = nseq; a.n = n; a.n_pad = (n + 31) / 32 * 32; a.heads = heads; a.ldq = ldq; a.ldk = ldk; a.scale = scale;
+  if (int e = check(a, dhead)) return e;
+  const int nw = waves_for(n);
+  dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
+  const size_t lds = (size_t)a.n_pad * dhead * 2;
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  if (dhead == 32) {
+    if (lds > 65536) hipFuncSetAttribute((const void*)attn_probs_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_probs_kernel<32>, grid, block, lds, (hipStream_t)stream, a, probs);
+  } else {
+    if (lds > 65536) hipFuncSetAttribute((const void*)attn_probs_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_probs_kernel<64>, grid, block, lds, (hipStream_t)stream, a, probs);
+  }
+  CTCLIP_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// Shared device helpers for the CT-CLIP gfx950 kernels (wave64, MFMA, LDS).
+// No CUDA compatibility layer: this code targets CDNA4 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 storage
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(8))) short short8v;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CTCLIP_CHECK_LAUNCH() \
+  do {                        \
+    hipError_t e_ = hipGetLastError(); \
+    return (int)e_;           \
+  } while (0)
+
+// ----- bf16 <-> f32 -------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) {
+  return __uint_as_float(((uint32_t)h) << 16);
+}
+// round-to-nearest-even; plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ----- wave-level reductions (64 lanes) -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ----- LDS transposed read (gfx950 ds_read_b64_tr_b16) -----------------------------------
+// Per 16-lane group: lane 4q+p supplies the address of (row q, cols 4p..4p+3) of a 4x16 block
+// of 16-bit elements; lane i receives column i, rows 0..3 in elements 0..3.
+__device__ __forceinline__ short4v lds_read_tr16(const void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (short4v __attribute__((address_space(3)))*)(uintptr_t)(uint32_t)(uintptr_t)lds_addr);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(short8v v) { return __builtin_bit_cast(bf16x8, v); }
+
+__device__ __forceinline__ bf16x8 join_tr(short4v lo, short4v hi) {
+  short8v r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// MFMA 32x32x16 bf16: D[32x32] += A[32x16] * B[16x32].
+//   lane l (r = l&31, h = l>>5) holds A[r][8h+j] and B[8h+j][r], j = 0..7.
+//   acc reg i holds D[(i&3) + 8*(i>>2) + 4h][r].
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// XCD-aware block-id remap (8 XCDs, round-robin dispatch): gives every XCD a contiguous run of
+// logical tile ids so neighbouring tiles share an L2.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}

@@ -1,0 +1,244 @@
+// HBM-bound elementwise / data-movement kernels: casts, GEGLU, GELU, token-layout permutes, means.
+// 16 bytes per lane everywhere; grid capped at 2048 blocks with a grid-stride loop.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ void unpack8(const uint4& r, float (&f)[8]) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 o;
+  o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+  o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
+  return o;
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const float4 a = ((const float4*)x)[2 * i], b = ((const float4*)x)[2 * i + 1];
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    ((uint4*)y)[i] = pack8(f);
+  }
+}
+
+// GEGLU, reference src/utils/attention.py:38-41: h = [val | gate] halves of width I; g = gelu(gate) * val
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ g, long rows,
+                                                        int I8, long ldh, long ldg) {
+  const long total = rows * I8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / I8;
+    const int c = (int)(i % I8);
+    float v[8], t[8], o[8];
+    unpack8(*(const uint4*)(h + r * ldh + c * 8), v);
+    unpack8(*(const uint4*)(h + r * ldh + (long)I8 * 8 + c * 8), t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = gelu_f(t[k]) * v[k];
+    *(uint4*)(g + r * ldg + c * 8) = pack8(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ dg, const bf16_t* __restrict__ h,
+                                                        bf16_t* __restrict__ dh, long rows, int I8, long lddg, long ldh) {
+  const long total = rows * I8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / I8;
+    const int c = (int)(i % I8);
+    float v[8], t[8], d[8], dv[8], dt[8];
+    unpack8(*(const uint4*)(h + r * ldh + c * 8), v);
+    unpack8(*(const uint4*)(h + r * ldh + (long)I8 * 8 + c * 8), t);
+    unpack8(*(const uint4*)(dg + r * lddg + c * 8), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      dv[k] = d[k] * gelu_f(t[k]);
+      dt[k] = d[k] * v[k] * gelu_grad_f(t[k]);
+    }
+    *(uint4*)(dh + r * ldh + c * 8) = pack8(dv);
+    *(uint4*)(dh + r * ldh + (long)I8 * 8 + c * 8) = pack8(dt);
+  }
+}
+
+// erf-GELU (transformers BertIntermediate)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ m, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    float v[8], o[8];
+    unpack8(((const uint4*)h)[i], v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = gelu_f(v[k]);
+    ((uint4*)m)[i] = pack8(o);
+  }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dm, const bf16_t* __restrict__ h,
+                                                       bf16_t* __restrict__ dh, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    float v[8], d[8], o[8];
+    unpack8(((const uint4*)h)[i], v);
+    unpack8(((const uint4*)dm)[i], d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = d[k] * gelu_grad_f(v[k]);
+    ((uint4*)dh)[i] = pack8(o);
+  }
+}
+
+// out[b, c, a, :] = in[b, a, c, :]   (f32 rows of D floats).  reference src/utils/ctvit.py:94-101 rearranges.
+__global__ __launch_bounds__(256) void swap_middle_kernel(const float* __restrict__ in, float* __restrict__ out, long B,
+                                                          int A, int C, int D4) {
+  const long total = B * A * C * D4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int d = (int)(i % D4);
+    long r = i / D4;  // output row index (b, c, a)
+    const int a = (int)(r % A);
+    r /= A;
+    const int c = (int)(r % C);
+    const long b = r / C;
+    ((float4*)out)[i] = ((const float4*)in)[((b * A + a) * C + c) * D4 + d];
+  }
+}
+
+// y[b, :] = mean_t x[b, t, :]  -> bf16 and/or f32.   reference src/models/ctclip.py:111
+__global__ __launch_bounds__(256) void mean_mid_kernel(const float* __restrict__ x, bf16_t* __restrict__ y16,
+                                                       float* __restrict__ y32, long B, int T, long F4) {
+  const long total = B * F4;
+  const float invT = 1.0f / (float)T;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / F4, f = i % F4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < T; ++t) {
+      const float4 v = ((const float4*)x)[(b * T + t) * F4 + f];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    s.x *= invT; s.y *= invT; s.z *= invT; s.w *= invT;
+    if (y32) ((float4*)y32)[i] = s;
+    if (y16) {
+      uint2 p;
+      p.x = pack_bf16x2(s.x, s.y);
+      p.y = pack_bf16x2(s.z, s.w);
+      ((uint2*)y16)[i] = p;
+    }
+  }
+}
+
+// dx[b, t, :] = dy[b, :] / T
+__global__ __launch_bounds__(256) void mean_mid_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long B,
+                                                           int T, long F4) {
+  const long total = B * T * F4;
+  const float invT = 1.0f / (float)T;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long f = i % F4, b = i / (F4 * T);
+    float4 v = ((const float4*)dy)[b * F4 + f];
+    v.x *= invT; v.y *= invT; v.z *= invT; v.w *= invT;
+    ((float4*)dx)[i] = v;
+  }
+}
+
+// y = a + b (f32) with optional bf16 shadow of the sum
+__global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ y, bf16_t* __restrict__ y16, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 u = ((const float4*)a)[i];
+    if (b) {
+      const float4 v = ((const float4*)b)[i];
+      u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+    }
+    if (y) ((float4*)y)[i] = u;
+    if (y16) {
+      uint2 p;
+      p.x = pack_bf16x2(u.x, u.y);
+      p.y = pack_bf16x2(u.z, u.w);
+      ((uint2*)y16)[i] = p;
+    }
+  }
+}
+
+inline unsigned grid_for(long work) {
+  long b = (work + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctclip_cast_f32_bf16(const float* x, void* y, long n, void* stream) {
+  if (n <= 0) return 0;
+  if (n & 7) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n / 8);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, long ldh, long ldg, void* stream) {
+  if (rows <= 0) return 0;
+  if ((inner & 7) || (ldh & 7) || (ldg & 7)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(rows * (inner / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)h, (bf16_t*)g, rows, inner / 8, ldh, ldg);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, long lddg, long ldh, void* stream) {
+  if (rows <= 0) return 0;
+  if ((inner & 7) || (ldh & 7) || (lddg & 7)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(rows * (inner / 8))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dg, (const bf16_t*)h, (bf16_t*)dh, rows, inner / 8, lddg, ldh);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_gelu_fwd(const void* h, void* m, long n, void* stream) {
+  if (n <= 0) return 0;
+  if (n & 7) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h,
+                     (bf16_t*)m, n / 8);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_gelu_bwd(const void* dm, const void* h, void* dh, long n, void* stream) {
+  if (n <= 0) return 0;
+  if (n & 7) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dm,
+                     (const bf16_t*)h, (bf16_t*)dh, n / 8);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_swap_middle_f32(const float* in, float* out, long B, int A, int C, int D, void* stream) {
+  if (B * A * C <= 0) return 0;
+  if (D & 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(swap_middle_kernel, dim3(grid_for(B * A * C * (D / 4))), dim3(256), 0, (hipStream_t)stream, in, out,
+                     B, A, C, D / 4);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_mean_mid_fwd(const float* x, void* y_bf16, float* y_f32, long B, int T, long F, void* stream) {
+  if (B * F <= 0) return 0;
+  if (F & 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mean_mid_kernel, dim3(grid_for(B * (F / 4))), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y_bf16,
+                     y_f32, B, T, F / 4);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_mean_mid_bwd(const float* dy, float* dx, long B, int T, long F, void* stream) {
+  if (B * F <= 0) return 0;
+  if (F & 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mean_mid_bwd_kernel, dim3(grid_for(B * T * (F / 4))), dim3(256), 0, (hipStream_t)stream, dy, dx, B,
+                     T, F / 4);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_add_f32(const float* a, const float* b, float* y, void* y_bf16, long n, void* stream) {
+  if (n <= 0) return 0;
+  if (n & 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, a, b, y, (bf16_t*)y_bf16,
+                     n / 4);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+}  // extern "C"

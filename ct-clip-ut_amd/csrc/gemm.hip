@@ -1,0 +1,274 @@
+// bf16 MFMA GEMM family for gfx950 (MI355X).
+//
+//   C[M,N] = alpha * opA(A)[M,K] * opB(B)[K,N]  (+ bias[N]) (+ residual[M,N]) -> act -> bf16 | f32 | f32 atomicAdd
+//
+// Operand layouts (no transposes are ever materialised in HBM):
+//   a_kmajor = 1 : A stored [M][K] (K contiguous)      0 : A stored [K][M] (M contiguous)
+//   b_kmajor = 1 : B stored [N][K] (nn.Linear weight)  0 : B stored [K][N]
+// which covers the three products of a linear layer:
+//   forward  y  = x  W^T   (1,1)      dgrad  dx = dy W   (1,0)      wgrad  dW = dy^T x  (0,0)
+//
+// Structure: 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile as
+// 2x2 v_mfma_f32_32x32x16_bf16 accumulators.  Global -> VGPR -> LDS staging, double-buffered
+// LDS (64 KiB), next tile's global loads issued before the MFMA block and written to LDS after it
+// (one barrier per K-step).  K-major tiles are stored [row][64] with a 16-byte-chunk XOR swizzle
+// (chunk ^ ((row>>1)&7)) so ds_read_b128 fragment reads are bank-conflict free; M/N-major tiles are
+// stored [k][128] with the dual-use swizzle (chunk ^ ((k&3)<<2 | (k>>2)&3)) and fragments are
+// fetched with ds_read_b64_tr_b16 (hardware transpose), also conflict free.
+// Block ids are remapped so each XCD's L2 sees a contiguous run of tiles (N fastest: blocks that
+// share an A row-panel run on one XCD).  split_k > 1 accumulates with f32 atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BKT = 64, NTHREADS = 256;
+constexpr int TILE_BYTES = BM * BKT * 2;  // 16 KiB per operand tile
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const float* bias;
+  const float* resid;
+  long lda, ldb, ldc, ldr;
+  int M, N, K;
+  int tiles_m, tiles_n, split_k, ktiles_per_split;
+  int c_fp32, atomic_out, act;
+  float alpha;
+  float* part_val;  // argmax epilogue: [N][n_parts]
+  int* part_idx;
+  int n_parts;
+};
+
+template <bool KM>
+__device__ __forceinline__ uint32_t tile_off(int rk, int chunk) {
+  if (KM) return (uint32_t)(rk * 128 + ((chunk ^ ((rk >> 1) & 7)) << 4));
+  return (uint32_t)(rk * 256 + ((chunk ^ (((rk & 3) << 2) | ((rk >> 2) & 3))) << 4));
+}
+
+template <bool KM>
+__device__ __forceinline__ void load_tile_regs(const bf16_t* __restrict__ base, long ld, int row0, int k0,
+                                               int R, int K, uint4 (&reg)[4], int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * NTHREADS + tid;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (KM) {
+      const int r = q >> 3, c = q & 7;
+      if (row0 + r < R && k0 + c * 8 < K) v = *(const uint4*)(base + (long)(row0 + r) * ld + k0 + c * 8);
+    } else {
+      const int k = q >> 4, c = q & 15;
+      if (k0 + k < K && row0 + c * 8 < R) v = *(const uint4*)(base + (long)(k0 + k) * ld + row0 + c * 8);
+    }
+    reg[i] = v;
+  }
+}
+
+template <bool KM>
+__device__ __forceinline__ void store_tile_lds(char* tile, const uint4 (&reg)[4], int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * NTHREADS + tid;
+    const uint32_t off = KM ? tile_off<true>(q >> 3, q & 7) : tile_off<false>(q >> 4, q & 15);
+    *(uint4*)(tile + off) = reg[i];
+  }
+}
+
+// MFMA operand fragment for rows rbase..rbase+31 of the tile, k-step s (16 k values).
+template <bool KM>
+__device__ __forceinline__ bf16x8 read_frag(const char* tile, int rbase, int s, int lane) {
+  if (KM) {
+    const int r = rbase + (lane & 31);
+    return *(const bf16x8*)(tile + tile_off<true>(r, 2 * s + (lane >> 5)));
+  } else {
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3, h = g >> 1;
+    const int m0 = rbase + 16 * (g & 1) + 4 * p;
+    const int klo = 16 * s + 8 * h + q;
+    const uint32_t sub = (uint32_t)((p & 1) * 8);
+    short4v lo = lds_read_tr16(tile + tile_off<false>(klo, m0 >> 3) + sub);
+    short4v hi = lds_read_tr16(tile + tile_off<false>(klo + 4, m0 >> 3) + sub);
+    return join_tr(lo, hi);
+  }
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <bool AKM, bool BKM, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = gridDim.x;
+  int bid = xcd_remap(blockIdx.x, nwg);
+  const int tn = bid % g.tiles_n;
+  bid /= g.tiles_n;
+  const int tm = bid % g.tiles_m;
+  const int ks = bid / g.tiles_m;
+
+  const int row0 = tm * BM, col0 = tn * BN;
+  const int nk_total = (g.K + BKT - 1) / BKT;
+  const int kt_begin = ks * g.ktiles_per_split;
+  const int kt_end = min(nk_total, kt_begin + g.ktiles_per_split);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kt_begin < kt_end) {
+    uint4 ra[4], rb[4];
+    load_tile_regs<AKM>(g.A, g.lda, row0, kt_begin * BKT, g.M, g.K, ra, tid);
+    load_tile_regs<BKM>(g.B, g.ldb, col0, kt_begin * BKT, g.N, g.K, rb, tid);
+    store_tile_lds<AKM>(smem, ra, tid);
+    store_tile_lds<BKM>(smem + TILE_BYTES, rb, tid);
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int cur = (kt - kt_begin) & 1;
+      const char* ta = smem + cur * 2 * TILE_BYTES;
+      const char* tb = ta + TILE_BYTES;
+      const bool more = (kt + 1) < kt_end;
+      if (more) {
+        load_tile_regs<AKM>(g.A, g.lda, row0, (kt + 1) * BKT, g.M, g.K, ra, tid);
+        load_tile_regs<BKM>(g.B, g.ldb, col0, (kt + 1) * BKT, g.N, g.K, rb, tid);
+      }
+#pragma unroll
+      for (int s = 0; s < BKT / 16; ++s) {
+        bf16x8 fa[2], fb[2];
+        fa[0] = read_frag<AKM>(ta, wm * 64, s, lane);
+        fa[1] = read_frag<AKM>(ta, wm * 64 + 32, s, lane);
+        fb[0] = read_frag<BKM>(tb, wn * 64, s, lane);
+        fb[1] = read_frag<BKM>(tb, wn * 64 + 32, s, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+      }
+      if (more) {
+        char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+        store_tile_lds<AKM>(na, ra, tid);
+        store_tile_lds<BKM>(na + TILE_BYTES, rb, tid);
+      }
+      __syncthreads();
+    }
+  }
+
+  const int half = lane >> 5, lc = lane & 31;
+
+  if (EPI == 1) {
+    // arg-max over the M (code) rows of this wave's 64x64 sub-tile, per N (token) column.
+    // part[(col) * n_parts + tm*2 + wm] = (best value, best row index); ties -> lowest row.
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = col0 + wn * 64 + j * 32 + lc;
+      float best = -INFINITY;
+      int besti = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + wm * 64 + i * 32 + acc_row(r, half);
+          const float v = acc[i][j][r];
+          if (row < g.M && (v > best || (v == best && row < besti))) { best = v; besti = row; }
+        }
+      const float ob = __shfl_xor(best, 32, 64);
+      const int oi = __shfl_xor(besti, 32, 64);
+      if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+      if (half == 0 && col < g.N) {
+        const long p = (long)col * g.n_parts + tm * 2 + wm;
+        g.part_val[p] = best;
+        g.part_idx[p] = besti;
+      }
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = col0 + wn * 64 + j * 32 + lc;
+      if (col >= g.N) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 64 + i * 32 + acc_row(r, half);
+        if (row >= g.M) continue;
+        float v = acc[i][j][r] * g.alpha;
+        if (g.atomic_out) {
+          if (ks == 0) {
+            v += bv;
+            if (g.resid) v += g.resid[(long)row * g.ldr + col];
+          }
+          atomicAdd((float*)g.C + (long)row * g.ldc + col, v);
+        } else {
+          v += bv;
+          if (g.resid) v += g.resid[(long)row * g.ldr + col];
+          if (g.act == 1) v = gelu_erf(v);
+          if (g.c_fp32) ((float*)g.C)[(long)row * g.ldc + col] = v;
+          else ((bf16_t*)g.C)[(long)row * g.ldc + col] = f32_to_bf16(v);
+        }
+      }
+    }
+}
+
+template <int EPI>
+int launch(const GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) {
+  const int nblk = g.tiles_m * g.tiles_n * g.split_k;
+  const size_t lds = 4 * TILE_BYTES;
+  dim3 grid(nblk), block(NTHREADS);
+  if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, EPI>), grid, block, lds, st, g);
+  else if (a_kmajor && !b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<true, false, EPI>), grid, block, lds, st, g);
+  else if (!a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, EPI>), grid, block, lds, st, g);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, EPI>), grid, block, lds, st, g);
+  return (int)hipGetLastError();
+}
+
+bool bad_layout(const void* p, long ld, int contiguous_extent) {
+  return (((uintptr_t)p) & 15) != 0 || (ld & 7) != 0 || (contiguous_extent & 7) != 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// See include/ctclip_hip.h for the contract.
+int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const float* resid,
+                     int M, int N, int K, long lda, long ldb, long ldc, long ldr,
+                     int a_kmajor, int b_kmajor, int c_fp32, int split_k, float alpha, int act,
+                     void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (bad_layout(A, lda, a_kmajor ? K : M) || bad_layout(B, ldb, b_kmajor ? K : N)) return (int)hipErrorInvalidValue;
+  if (split_k > 1 && (!c_fp32 || act != 0)) return (int)hipErrorInvalidValue;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  const int nk = (K + BKT - 1) / BKT;
+  if (split_k < 1) split_k = 1;
+  if (split_k > nk) split_k = nk;
+  g.ktiles_per_split = (nk + split_k - 1) / split_k;
+  g.split_k = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
+  g.c_fp32 = c_fp32; g.atomic_out = (split_k > 1) ? 1 : 0; g.act = act; g.alpha = alpha;
+  return launch<0>(g, a_kmajor, b_kmajor, (hipStream_t)stream);
+}
+
+// scores[m][n] = sum_k A[m][k] B[n][k]; for every column n writes the arg-max over the rows of each
+// 64-row slab: part_val/part_idx are [N][n_parts], n_parts = 2*ceil(M/128).
+int ctclip_gemm_argmax_partial(const void* A, const void* B, float* part_val, int* part_idx,
+                               int M, int N, int K, long lda, long ldb, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (bad_layout(A, lda, K) || bad_layout(B, ldb, K)) return (int)hipErrorInvalidValue;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  g.split_k = 1; g.ktiles_per_split = (K + BKT - 1) / BKT; g.alpha = 1.f;
+  g.part_val = part_val; g.part_idx = part_idx; g.n_parts = 2 * g.tiles_m;
+  return launch<1>(g, 1, 1, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+// LayerNorm (with / without bias) and per-head cosine normalisation, forward + backward.
+// All HBM-bound: one wave per row, float4 / 16-byte accesses, rows kept in registers between the
+// statistics pass and the normalise pass (dim <= 4096), column reductions (dgamma, dbeta, dscale)
+// accumulated per wave across a grid-stride loop and flushed with one f32 atomic per column.
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAXV = 16;  // float4 per lane -> dim <= 64*4*16 = 4096
+
+// reference src/utils/attention.py:27-34,46 ; src/utils/ctvit.py:49,51 ; transformers BertLayerNorm
+template <int LN_NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ y16,
+                                                            float* __restrict__ y32, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int rows, int dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = dim >> 2;  // float4 count
+  const float4* xr = (const float4*)(x + (long)row * dim);
+  float4 v[LN_NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      v[i] = xr[c];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mu = wave_sum(s) / (float)dim;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)dim + eps);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+#pragma unroll
+  for (int i = 0; i < LN_NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 g = ((const float4*)gamma)[c];
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (beta) b = ((const float4*)beta)[c];
+      float4 o;
+      o.x = (v[i].x - mu) * rs * g.x + b.x;
+      o.y = (v[i].y - mu) * rs * g.y + b.y;
+      o.z = (v[i].z - mu) * rs * g.z + b.z;
+      o.w = (v[i].w - mu) * rs * g.w + b.w;
+      if (y32) ((float4*)(y32 + (long)row * dim))[c] = o;
+      if (y16) {
+        uint2 p;
+        p.x = pack_bf16x2(o.x, o.y);
+        p.y = pack_bf16x2(o.z, o.w);
+        ((uint2*)(y16 + (long)row * dim))[c] = p;
+      }
+    }
+  }
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+// dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy
+template <int LN_NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, bf16_t* __restrict__ dx16,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rows, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int nv = dim >> 2;
+  float4 ag[LN_NV], ab[LN_NV];
+#pragma unroll
+  for (int i = 0; i < LN_NV; ++i) {
+    ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row = wave_global; row < rows; row += nwaves) {
+    const float mu = mean[row], rs = rstd[row];
+    const float4* xr = (const float4*)(x + (long)row * dim);
+    const float4* dr = (const float4*)(dy + (long)row * dim);
+    float4 xh[LN_NV], gg[LN_NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_NV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const float4 xv = xr[c], dv = dr[c], gm = ((const float4*)gamma)[c];
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        gg[i] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
+        s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
+        s2 += (gg[i].x * xh[i].x + gg[i].y * xh[i].y) + (gg[i].z * xh[i].z + gg[i].w * xh[i].w);
+        ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+        ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)dim, m2 = wave_sum(s2) / (float)dim;
+#pragma unroll
+    for (int i = 0; i < LN_NV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        float4 o;
+        o.x = rs * (gg[i].x - m1 - xh[i].x * m2);
+        o.y = rs * (gg[i].y - m1 - xh[i].y * m2);
+        o.z = rs * (gg[i].z - m1 - xh[i].z * m2);
+        o.w = rs * (gg[i].w - m1 - xh[i].w * m2);
+        if (dres) {
+          const float4 r = ((const float4*)(dres + (long)row * dim))[c];
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (dx) ((float4*)(dx + (long)row * dim))[c] = o;
+        if (dx16) {
+          uint2 p;
+          p.x = pack_bf16x2(o.x, o.y);
+          p.y = pack_bf16x2(o.z, o.w);
+          ((uint2*)(dx16 + (long)row * dim))[c] = p;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      float* pg = dgamma + c * 4;
+      atomicAdd(pg + 0, ag[i].x); atomicAdd(pg + 1, ag[i].y); atomicAdd(pg + 2, ag[i].z); atomicAdd(pg + 3, ag[i].w);
+      if (dbeta) {
+        float* pb = dbeta + c * 4;
+        atomicAdd(pb + 0, ab[i].x); atomicAdd(pb + 1, ab[i].y); atomicAdd(pb + 2, ab[i].z); atomicAdd(pb + 3, ab[i].w);
+      }
+    }
+  }
+}
+
+// ---- per-head cosine normalisation: y = x / max(|x|,1e-12) * scale[d] * mult --------------------
+// reference src/utils/attention.py:151-153 (+ the fixed `scale = 8` of :98,155 folded into q via mult)
+// LPH lanes share one (row, head); each lane owns 8 consecutive bf16 (16 bytes).  D = 8*LPH.
+template <int LPH>
+__global__ __launch_bounds__(256) void headnorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                           bf16_t* __restrict__ y, float* __restrict__ inv_norm,
+                                                           long npairs, int H, long ldx, long ldy, float mult) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long pair = gid / LPH;
+  const int sub = (int)(gid % LPH);
+  const bool ok = pair < npairs;
+  const long row = ok ? pair / H : 0;
+  const int head = ok ? (int)(pair % H) : 0;
+  const int D = LPH * 8;
+  float f[8];
+  uint4 raw = make_uint4(0, 0, 0, 0);
+  if (ok) raw = *(const uint4*)(x + row * ldx + head * D + sub * 8);
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    ss += f[2 * i] * f[2 * i] + f[2 * i + 1] * f[2 * i + 1];
+  }
+#pragma unroll
+  for (int o = LPH >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+  if (!ok) return;
+  if (sub == 0) inv_norm[pair] = inv;
+  uint4 o;
+  uint32_t* ow = (uint32_t*)&o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float s0 = scale[sub * 8 + 2 * i] * mult, s1 = scale[sub * 8 + 2 * i + 1] * mult;
+    ow[i] = pack_bf16x2(f[2 * i] * inv * s0, f[2 * i + 1] * inv * s1);
+  }
+  *(uint4*)(y + row * ldy + head * D + sub * 8) = o;
+}
+
+// dx = inv * (du - u (u . du)),  u = x*inv,  du = dy * scale * mult ;  dscale[d] += sum dy * u * mult
+template <int LPH>
+__global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                           const float* __restrict__ inv_norm, const float* __restrict__ scale,
+                                                           bf16_t* __restrict__ dx, float* __restrict__ dscale,
+                                                           long npairs, int H, long lddy, long ldx, long lddx, float mult) {
+  __shared__ float red[LPH * 8];
+  const int D = LPH * 8;
+  if (threadIdx.x < D) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int sub = threadIdx.x % LPH;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const long stride = (long)gridDim.x * (256 / LPH);
+  // every lane of an LPH group walks the same pair sequence, so the shuffles below stay convergent
+  const long iters = (npairs + stride - 1) / stride;
+  long pair = (long)blockIdx.x * (256 / LPH) + threadIdx.x / LPH;
+  for (long it = 0; it < iters; ++it, pair += stride) {
+    const bool ok = pair < npairs;
+    const long row = ok ? pair / H : 0;
+    const int head = ok ? (int)(pair % H) : 0;
+    uint4 rx = make_uint4(0, 0, 0, 0), rd = make_uint4(0, 0, 0, 0);
+    float inv = 0.f;
+    if (ok) {
+      rx = *(const uint4*)(x + row * ldx + head * D + sub * 8);
+      rd = *(const uint4*)(dy + row * lddy + head * D + sub * 8);
+      inv = inv_norm[pair];
+    }
+    const uint32_t wx[4] = {rx.x, rx.y, rx.z, rx.w}, wd[4] = {rd.x, rd.y, rd.z, rd.w};
+    float u[8], du[8], dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x0 = __uint_as_float(wx[i] << 16), x1 = __uint_as_float(wx[i] & 0xffff0000u);
+      const float d0 = __uint_as_float(wd[i] << 16), d1 = __uint_as_float(wd[i] & 0xffff0000u);
+      u[2 * i] = x0 * inv; u[2 * i + 1] = x1 * inv;
+      du[2 * i] = d0 * scale[sub * 8 + 2 * i] * mult; du[2 * i + 1] = d1 * scale[sub * 8 + 2 * i + 1] * mult;
+      acc[2 * i] += d0 * u[2 * i] * mult; acc[2 * i + 1] += d1 * u[2 * i + 1] * mult;
+      dot += u[2 * i] * du[2 * i] + u[2 * i + 1] * du[2 * i + 1];
+    }
+#pragma unroll
+    for (int o = LPH >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if (ok) {
+      uint4 o;
+      uint32_t* ow = (uint32_t*)&o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        ow[i] = pack_bf16x2(inv * (du[2 * i] - u[2 * i] * dot), inv * (du[2 * i + 1] - u[2 * i + 1] * dot));
+      *(uint4*)(dx + row * lddx + head * D + sub * 8) = o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) atomicAdd(&red[sub * 8 + i], acc[i]);
+  __syncthreads();
+  if (threadIdx.x < D) atomicAdd(&dscale[threadIdx.x], red[threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                         float* mean, float* rstd, int rows, int dim, float eps, void* stream) {
+  if (rows <= 0) return 0;
+  if ((dim & 3) || dim > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
+#define LN_FWD(NV)                                                                                              \
+  hipLaunchKernelGGL(layernorm_fwd_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, \
+                     beta, (bf16_t*)y_bf16, y_f32, mean, rstd, rows, dim, eps)
+  const int nv = (dim / 4 + 63) / 64;
+  if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 3) LN_FWD(3); else if (nv <= 4) LN_FWD(4); else LN_FWD(16);
+#undef LN_FWD
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                         const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int rows, int dim,
+                         void* stream) {
+  if (rows <= 0) return 0;
+  if ((dim & 3) || dim > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+#define LN_BWD(NV)                                                                                                 \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, \
+                     rstd, dres, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim)
+  const int nv = (dim / 4 + 63) / 64;
+  if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(16);
+#undef LN_BWD
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_norm, long rows, int heads, int dhead,
+                        long ldx, long ldy, float mult, void* stream) {
+  const long npairs = rows * heads;
+  if (npairs <= 0) return 0;
+  if (dhead != 32 && dhead != 64) return (int)hipErrorInvalidValue;
+  const int lph = dhead / 8;
+  const long threads = npairs * lph;
+  dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+  if (lph == 4)
+    hipLaunchKernelGGL(headnorm_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, scale, (bf16_t*)y,
+                       inv_norm, npairs, heads, ldx, ldy, mult);
+  else
+    hipLaunchKernelGGL(headnorm_fwd_kernel<8>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, scale, (bf16_t*)y,
+                       inv_norm, npairs, heads, ldx, ldy, mult);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
+                        float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
+                        void* stream) {
+  const long npairs = rows * heads;
+  if (npairs <= 0) return 0;
+  if (dhead != 32 && dhead != 64) return (int)hipErrorInvalidValue;
+  const int lph = dhead / 8;
+  long blocks = (npairs + (256 / lph) - 1) / (256 / lph);
+  if (blocks > 2048) blocks = 2048;
+  dim3 grid((unsigned)blocks), block(256);
+  if (lph == 4)
+    hipLaunchKernelGGL(headnorm_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
+                       inv_norm, scale, (bf16_t*)dx, dscale, npairs, heads, lddy, ldx, lddx, mult);
+  else
+    hipLaunchKernelGGL(headnorm_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
+                       inv_norm, scale, (bf16_t*)dx, dscale, npairs, heads, lddy, ldx, lddx, mult);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+}  // extern "C"

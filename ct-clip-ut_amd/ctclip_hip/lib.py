@@ -1,0 +1,109 @@
+"""ctypes loader for libctclip_hip.so.  Prototypes are parsed from include/ctclip_hip.h so the header is
+the single source of truth for the C ABI."""
+import ctypes
+import os
+import re
+
+import torch
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(PKG))
+HEADER = os.path.join(REPO, "include", "ctclip_hip.h")
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(PKG, "libctclip_hip.so")
+
+
+_CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
+
+
+def parse_header(path=HEADER):
+    """-> {name: [(ctype, argname, is_pointer)]} for every `int ctclip_*(...)` declaration."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(ctclip_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
+        args = []
+        for a in m.group(2).split(","):
+            a = " ".join(a.split())
+            ptr = "*" in a
+            name = re.findall(r"(\w+)\s*$", a)[0]
+            base = a.replace("const", "").replace("*", " ").split()[0]
+            args.append((ctypes.c_void_p if ptr else _CTYPES[base], name, ptr))
+        protos[m.group(1)] = args
+    return protos
+
+
+class _Hip:
+    """Attribute access gives a checked wrapper: tensors -> device pointers, None -> NULL, the trailing
+    `stream` argument defaults to torch's current stream, a non-zero return raises RuntimeError."""
+
+    def __init__(self):
+        self._dll = None
+        self._protos = None
+        self._fns = {}
+
+    def _ensure(self):
+        if self._dll is not None:
+            return
+        path = library_path()
+        if not os.path.exists(path):
+            raise HipLibraryMissing(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the CT-CLIP hot path.")
+        self._dll = ctypes.CDLL(path)
+        self._protos = parse_header()
+
+    def symbols(self):
+        self._ensure()
+        return sorted(self._protos)
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        self._ensure()
+        if name in self._fns:
+            return self._fns[name]
+        full = name if name.startswith("ctclip_") else "ctclip_" + name
+        if full not in self._protos:
+            raise AttributeError(f"{full} is not declared in include/ctclip_hip.h")
+        proto = self._protos[full]
+        cfn = getattr(self._dll, full)
+        cfn.restype = ctypes.c_int
+        cfn.argtypes = [t for t, _, _ in proto]
+        nargs = len(proto)
+        has_stream = proto[-1][1] == "stream"
+
+        def call(*args):
+            if has_stream and len(args) == nargs - 1:
+                args = (*args, torch.cuda.current_stream().cuda_stream)
+            if len(args) != nargs:
+                raise TypeError(f"{full} takes {nargs} arguments ({[n for _, n, _ in proto]}), got {len(args)}")
+            conv = []
+            for a, (_, an, ptr) in zip(args, proto):
+                if ptr:
+                    if a is None:
+                        conv.append(None)
+                    elif isinstance(a, torch.Tensor):
+                        if not a.is_cuda:
+                            raise RuntimeError(f"{full}: argument `{an}` is a CPU tensor; the HIP path has no CPU fallback")
+                        conv.append(a.data_ptr())
+                    else:
+                        conv.append(int(a))
+                else:
+                    conv.append(a)
+            err = cfn(*conv)
+            if err != 0:
+                raise RuntimeError(f"{full} failed with hipError_t {err}")
+
+        call.__name__ = full
+        self._fns[name] = call
+        return call
+
+
+hip = _Hip()

@@ -1,0 +1,275 @@
+"""GPU unit tests of the C-ABI kernels against plain PyTorch fp32 math on the same (bf16-rounded) inputs.
+
+Tolerances: kernels take bf16 operands and accumulate in f32; bf16 outputs carry 2^-9 relative rounding,
+so bf16 results are compared at rtol 2e-2 / f32 results at 2e-3 against an fp32 reference computed from
+the SAME bf16-rounded inputs.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from ctclip_hip.lib import hip as h
+    assert torch.cuda.is_available()
+    return h
+
+
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def bf(x):
+    return x.to(torch.bfloat16).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def check(name, got, ref, tol):
+    e = relerr(got, ref)
+    print(f"  {name}: max-rel-to-peak err {e:.3e} (tol {tol:.1e})")
+    assert math.isfinite(e) and e <= tol, f"{name}: {e} > {tol}"
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("akm,bkm", [(1, 1), (1, 0), (0, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 72), (512, 256, 512), (96, 2816, 64), (128, 128, 4032)])
+def test_gemm_layouts(hip, akm, bkm, M, N, K):
+    if not akm and M % 8:
+        M = (M + 7) // 8 * 8
+    A = bf(rnd(M, K, seed=1)) if akm else bf(rnd(K, M, seed=1))
+    B = bf(rnd(N, K, seed=2)) if bkm else bf(rnd(K, N, seed=2))
+    Am = A.float() if akm else A.float().t()
+    Bm = B.float().t() if bkm else B.float()
+    ref = Am @ Bm
+    C = torch.empty(M, N, device=DEV, dtype=torch.float32)
+    hip.gemm_bf16(A, B, C, None, None, M, N, K, A.stride(0), B.stride(0), N, 0, akm, bkm, 1, 1, 1.0, 0)
+    check(f"gemm f32 ({akm},{bkm}) {M}x{N}x{K}", C, ref, 2e-3)
+    C16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16(A, B, C16, None, None, M, N, K, A.stride(0), B.stride(0), N, 0, akm, bkm, 0, 1, 1.0, 0)
+    check(f"gemm bf16 ({akm},{bkm})", C16, ref, 1e-2)
+
+
+def test_gemm_mfma_orientation_asymmetric(hip):
+    """A = I with an asymmetric B catches a transposed C write (guide: 'always A=I-check')."""
+    n = 128
+    A = bf(torch.eye(n, device=DEV))
+    Bw = bf(torch.arange(n * n, device=DEV, dtype=torch.float32).reshape(n, n) % 251)   # exact in bf16
+    C = torch.empty(n, n, device=DEV, dtype=torch.float32)
+    hip.gemm_bf16(A, Bw, C, None, None, n, n, n, n, n, n, 0, 1, 1, 1, 1, 1.0, 0)       # C = I @ Bw^T
+    assert torch.equal(C, Bw.float().t())
+    hip.gemm_bf16(A, Bw, C, None, None, n, n, n, n, n, n, 0, 1, 0, 1, 1, 1.0, 0)       # C = I @ Bw
+    assert torch.equal(C, Bw.float())
+    hip.gemm_bf16(Bw, A, C, None, None, n, n, n, n, n, n, 0, 0, 1, 1, 1, 1.0, 0)       # C = Bw^T @ I
+    assert torch.equal(C, Bw.float().t())
+
+
+def test_gemm_epilogues_and_splitk(hip):
+    M, N, K = 300, 264, 1024
+    A, B = bf(rnd(M, K, seed=3)), bf(rnd(N, K, seed=4))
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    ref = A.float() @ B.float().t()
+    C = torch.empty(M, N, device=DEV)
+    hip.gemm_bf16(A, B, C, bias, res, M, N, K, K, K, N, N, 1, 1, 1, 1, 0.5, 0)
+    check("bias+resid+alpha", C, 0.5 * ref + bias + res, 2e-3)
+    hip.gemm_bf16(A, B, C, bias, None, M, N, K, K, K, N, 0, 1, 1, 1, 1, 1.0, 1)
+    check("gelu", C, torch.nn.functional.gelu(ref + bias), 2e-3)
+    C.copy_(res)
+    hip.gemm_bf16(A, B, C, bias, None, M, N, K, K, K, N, 0, 1, 1, 1, 5, 1.0, 0)
+    check("split-k atomic accumulate", C, ref + bias + res, 2e-3)
+    # strided output / operand views (ld > extent)
+    big = torch.zeros(M, N + 24, device=DEV)
+    hip.gemm_bf16(A, B, big, None, None, M, N, K, K, K, N + 24, 0, 1, 1, 1, 1, 1.0, 0)
+    check("ldc > N", big[:, :N], ref, 2e-3)
+    assert float(big[:, N:].abs().max()) == 0.0
+
+
+def test_gemm_argmax_partial(hip):
+    C_, T, K = 320, 200, 64
+    E = bf(torch.nn.functional.normalize(rnd(C_, K, seed=7), dim=-1))
+    X = bf(torch.nn.functional.normalize(rnd(T, K, seed=8), dim=-1))
+    parts = 2 * ((C_ + 127) // 128)
+    pv = torch.full((T, parts), float("nan"), device=DEV)
+    pi = torch.full((T, parts), -1, device=DEV, dtype=torch.int32)
+    hip.gemm_argmax_partial(E, X, pv, pi, C_, T, K, K, K)
+    scores = X.float() @ E.float().t()                       # [T, C]
+    best = pv.argmax(dim=1)
+    idx = pi.gather(1, best[:, None])[:, 0].long()
+    ref_idx = scores.argmax(dim=1)
+    got_val = scores.gather(1, idx[:, None])[:, 0]
+    ref_val = scores.max(dim=1).values
+    assert float((ref_val - got_val).max()) <= 1e-5, "selected code must attain the max score (ties aside)"
+    assert float((idx == ref_idx).float().mean()) > 0.99
+
+
+# ---------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,dim,with_beta", [(37, 512, False), (130, 768, True), (9, 56, True), (5, 4000, True)])
+def test_layernorm_fwd_bwd(hip, rows, dim, with_beta):
+    x = (rnd(rows, dim, seed=9) * 2 + 0.5).requires_grad_(True)
+    gm = (1 + 0.3 * rnd(dim, seed=10)).requires_grad_(True)
+    bt = (0.2 * rnd(dim, seed=11)).requires_grad_(True) if with_beta else None
+    ref = torch.nn.functional.layer_norm(x, (dim,), gm, bt, 1e-5)
+    y16 = torch.empty(rows, dim, device=DEV, dtype=torch.bfloat16)
+    y32 = torch.empty(rows, dim, device=DEV)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    hip.layernorm_fwd(x.detach(), gm.detach(), None if bt is None else bt.detach(), y16, y32, mean, rstd, rows, dim, 1e-5)
+    check("ln y32", y32, ref, 1e-5)
+    check("ln y16", y16, ref, 1e-2)
+    dy, dres = rnd(rows, dim, seed=12), rnd(rows, dim, seed=13)
+    ref.backward(dy)
+    dx = torch.empty(rows, dim, device=DEV)
+    dx16 = torch.empty(rows, dim, device=DEV, dtype=torch.bfloat16)
+    dg, db = torch.zeros(dim, device=DEV), torch.zeros(dim, device=DEV)
+    hip.layernorm_bwd(dy, x.detach(), gm.detach(), mean, rstd, dres, dx, dx16, dg, db if with_beta else None, rows, dim)
+    check("ln dx", dx, x.grad + dres, 2e-5)
+    check("ln dx16", dx16, x.grad + dres, 1e-2)
+    check("ln dgamma", dg, gm.grad, 2e-5)
+    if with_beta:
+        check("ln dbeta", db, bt.grad, 2e-5)
+
+
+@pytest.mark.parametrize("D", [32, 64])
+def test_headnorm_fwd_bwd(hip, D):
+    rows, H, mult = 77, 3, 8.0
+    x = bf(rnd(rows, H * D + 16, seed=14))[:, : H * D]                   # strided view
+    sc = 1 + 0.3 * rnd(D, seed=15)
+    xr = x.float().reshape(rows, H, D).requires_grad_(True)
+    scr = sc.clone().requires_grad_(True)
+    ref = torch.nn.functional.normalize(xr, dim=-1) * scr * mult
+    y = torch.empty(rows, H * D, device=DEV, dtype=torch.bfloat16)
+    inv = torch.empty(rows, H, device=DEV)
+    hip.headnorm_fwd(x, sc, y, inv, rows, H, D, x.stride(0), H * D, mult)
+    check("headnorm y", y.float().reshape(rows, H, D), ref, 1e-2)
+    dy = bf(rnd(rows, H * D, seed=16))
+    ref.backward(dy.float().reshape(rows, H, D))
+    dx = torch.empty(rows, H * D, device=DEV, dtype=torch.bfloat16)
+    ds = torch.zeros(D, device=DEV)
+    hip.headnorm_bwd(dy, x, inv, sc, dx, ds, rows, H, D, H * D, x.stride(0), H * D, mult)
+    check("headnorm dx", dx.float().reshape(rows, H, D), xr.grad, 1e-2)
+    check("headnorm dscale", ds, scr.grad, 1e-3)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, bias, mask, scale):
+    s = torch.einsum("shid,shjd->shij", q, k) * scale
+    if bias is not None:
+        s = s + bias[None]
+    if mask is not None:
+        s = s + mask[:, None, None, :]
+    p = s.softmax(-1)
+    return torch.einsum("shij,shjd->shid", p, v), p
+
+
+@pytest.mark.parametrize("nseq,n,H,D,use_bias,use_mask", [
+    (3, 576, 8, 32, True, False),      # CT-ViT spatial
+    (40, 24, 8, 32, False, False),     # CT-ViT temporal
+    (4, 128, 12, 64, False, True),     # BERT L=128
+    (2, 40, 2, 32, True, False),       # ragged: n not a multiple of 32
+    (2, 6, 4, 32, True, True),         # n % 4 != 0
+    (1, 512, 2, 64, False, True),      # BERT L=512 (128 KiB of LDS)
+])
+def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask):
+    scale = 1.0 if D == 32 else 1.0 / math.sqrt(D)
+    ld = H * D
+    q, k, v = (rnd(nseq * n, ld, seed=s) for s in (20, 21, 22))
+    if D == 32:   # what ctclip_headnorm_fwd feeds the kernel: unit rows per head, q carries the fixed scale 8
+        unit = lambda t: torch.nn.functional.normalize(t.reshape(nseq * n, H, D), dim=-1).reshape(nseq * n, ld)
+        q, k = unit(q) * 8.0, unit(k)
+    q, k, v = bf(q), bf(k), bf(v)
+    do = bf(rnd(nseq * n, ld, seed=23))
+    bias = rnd(H, n, n, seed=24) if use_bias else None
+    mask = None
+    if use_mask:
+        lens = torch.randint(max(1, n // 3), n + 1, (nseq,), generator=torch.Generator().manual_seed(5))
+        lens[0] = n
+        mask = ((torch.arange(n)[None] >= lens[:, None]).float() * torch.finfo(torch.float32).min).to(DEV)
+    sp = lambda t: t.float().reshape(nseq, n, H, D).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    qr, kr, vr = sp(q), sp(k), sp(v)
+    br = bias.clone().requires_grad_(True) if use_bias else None
+    oref, pref = attn_ref(qr, kr, vr, br, mask, scale)
+    o = torch.empty(nseq * n, ld, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(nseq, H, n, device=DEV)
+    hip.attn_fwd(q, k, v, o, lse, bias, mask, nseq, n, H, D, ld, ld, ld, ld, scale)
+    og = o.float().reshape(nseq, n, H, D).permute(0, 2, 1, 3)
+    check("attn out", og, oref, 2e-2)
+    probs = torch.empty(nseq, H, n, n, device=DEV)
+    hip.attn_probs(q, k, lse, bias, mask, probs, nseq, n, H, D, ld, ld, scale)
+    check("attn probs", probs, pref, 2e-2)
+
+    oref.backward(do.float().reshape(nseq, n, H, D).permute(0, 2, 1, 3))
+    dq, dk, dv = (torch.empty(nseq * n, ld, device=DEV, dtype=torch.bfloat16) for _ in range(3))
+    delta = torch.empty(nseq, H, n, device=DEV)
+    dbias = torch.zeros(H, n, n, device=DEV) if use_bias else None
+    hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, mask, dbias, None, None, 0, nseq, n, H, D,
+                 ld, ld, ld, ld, ld, ld, ld, ld, scale)
+    un = lambda t: t.float().reshape(nseq, n, H, D).permute(0, 2, 1, 3)
+    check("attn dq", un(dq), qr.grad, 3e-2)
+    check("attn dk", un(dk), kr.grad, 3e-2)
+    check("attn dv", un(dv), vr.grad, 3e-2)
+    if use_bias:
+        check("attn dbias dense", dbias, br.grad, 3e-2)
+        # table mode: bias[h,i,j] = table[h, relidx[i,j]]; d(table) = scatter-add of d(bias)
+        R = 37
+        relidx = torch.randint(0, R, (n, n), generator=torch.Generator().manual_seed(3)).to(DEV)
+        dt = torch.zeros(H, R, device=DEV)
+        hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, mask, None, relidx.to(torch.uint16), dt, R,
+                     nseq, n, H, D, ld, ld, ld, ld, ld, ld, ld, ld, scale)
+        ref_t = torch.zeros(H, R, device=DEV).index_add_(1, relidx.reshape(-1), br.grad.reshape(H, -1))
+        check("attn dbias table", dt, ref_t, 3e-2)
+
+
+# ---------------------------------------------------------------------------------------------- elementwise
+def test_elementwise(hip):
+    rows, I = 50, 152
+    h = bf(rnd(rows, 2 * I, seed=30))
+    val, gate = h.float()[:, :I].clone().requires_grad_(True), h.float()[:, I:].clone().requires_grad_(True)
+    ref = torch.nn.functional.gelu(gate) * val
+    g = torch.empty(rows, I, device=DEV, dtype=torch.bfloat16)
+    hip.geglu_fwd(h, g, rows, I, 2 * I, I)
+    check("geglu", g, ref, 1e-2)
+    dg = bf(rnd(rows, I, seed=31))
+    ref.backward(dg.float())
+    dh = torch.empty_like(h)
+    hip.geglu_bwd(dg, h, dh, rows, I, I, 2 * I)
+    check("geglu dval", dh[:, :I], val.grad, 1e-2)
+    check("geglu dgate", dh[:, I:], gate.grad, 1e-2)
+
+    x = h.float().clone().requires_grad_(True)
+    r = torch.nn.functional.gelu(x)
+    m = torch.empty_like(h)
+    hip.gelu_fwd(h, m, h.numel())
+    check("gelu", m, r, 1e-2)
+    r.backward(torch.ones_like(r))
+    dm = bf(torch.ones_like(r))
+    hip.gelu_bwd(dm, h, dh, h.numel())
+    check("gelu bwd", dh, x.grad, 1e-2)
+
+    t = rnd(3, 4, 5, 8, seed=32)
+    out = torch.empty(3, 5, 4, 8, device=DEV)
+    hip.swap_middle_f32(t, out, 3, 4, 5, 8)
+    assert torch.equal(out, t.permute(0, 2, 1, 3).contiguous())
+    y32 = torch.empty(3, 40, device=DEV)
+    y16 = torch.empty(3, 40, device=DEV, dtype=torch.bfloat16)
+    hip.mean_mid_fwd(t, y16, y32, 3, 4, 40)
+    check("mean", y32, t.reshape(3, 4, 40).mean(1), 1e-6)
+    dx = torch.empty(3, 4, 40, device=DEV)
+    hip.mean_mid_bwd(y32, dx, 3, 4, 40)
+    check("mean bwd", dx, (y32 / 4)[:, None].expand(3, 4, 40), 1e-6)
+    a, b = rnd(64, seed=33), rnd(64, seed=34)
+    s32, s16 = torch.empty(64, device=DEV), torch.empty(64, device=DEV, dtype=torch.bfloat16)
+    hip.add_f32(a, b, s32, s16, 64)
+    assert torch.equal(s32, a + b)
+    c16 = torch.empty(64, device=DEV, dtype=torch.bfloat16)
+    hip.cast_f32_bf16(a, c16, 64)
+    assert torch.equal(c16, a.to(torch.bfloat16))
