@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""CT-CLIP contrastive training-step benchmark (BASELINE.json metric: CT-volume-report pairs/s, 480x480x240 bf16).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A step = CTClipTrainer.train_step on one synthetic batch already resident in HBM: zero_grad, CT-ViT + BERT forward,
+similarity matrix + symmetric InfoNCE, backward, RCCL gradient all-reduce (N>1), fused clip(0.5)+Adam, loss.item().
+Workload (BASELINE configs[1]): CT-ViT base (dim 512, 4+4 layers, 8x32 heads, codebook 8192) + BERT-base-shaped text
+encoder (12x768, the shape of CXR-BERT), 480x480x240 bf16 volumes, 128-token reports, random-init weights.
+Rank 0 prints ONE json line (see README / DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "ct-clip-ut_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+VIT = dict(dim=512, codebook_size=8192, image_size=480, patch_size=20, temporal_patch_size=10, spatial_depth=4,
+           temporal_depth=4, dim_head=32, heads=8)                      # reference src/train_ctclip.py:19-29
+TEXT = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, vocab_size=30522,
+            max_position_embeddings=512, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+
+def build_model(vit_cfg, text_cfg, dim_latent=512):
+    from transformers import BertConfig, BertModel
+    from models.ctclip import CTCLIP
+    from utils.ctvit import CTViT
+    torch.manual_seed(0)
+    grid = vit_cfg["image_size"] // vit_cfg["patch_size"]
+    return CTCLIP(text_encoder=BertModel(BertConfig(**text_cfg)), image_encoder=CTViT(**vit_cfg),
+                  dim_text=text_cfg["hidden_size"], dim_image=grid * grid * vit_cfg["dim"], dim_latent=dim_latent)
+
+
+def synthetic_batch(B, depth, size, L, vocab, device, rank, dtype=torch.bfloat16):
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    vol = (torch.randn(B, 1, depth, size, size, generator=g, device=device) * 0.5).clamp_(-1, 1).to(dtype)
+    gt = torch.Generator().manual_seed(4321 + rank)
+    ids = torch.randint(0, vocab, (B, L), generator=gt)
+    lens = torch.randint(L // 4, L + 1, (B,), generator=gt)
+    mask = (torch.arange(L)[None] < lens[:, None]).long()
+    txt = {"input_ids": ids.to(device), "token_type_ids": torch.zeros_like(ids).to(device), "attention_mask": mask.to(device)}
+    return vol, txt
+
+
+def cpu_baseline(model, depth, size, L, vocab, max_seconds=60.0):
+    """The oracle (oracle/ctclip_oracle.py, op-for-op f32 restatement of the reference) on the host cores: one pair,
+    one full training step (fwd + bwd + clip + Adam) at the production shape.  Reported, not optimised."""
+    from oracle import ctclip_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    st = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    vol, txt = synthetic_batch(1, depth, size, L, vocab, torch.device("cpu"), 0, dtype=torch.float32)
+    cfg = dict(VIT, text_layers=TEXT["num_hidden_layers"], text_heads=TEXT["num_attention_heads"])
+    frozen = [k for k in st if k.endswith(".beta") or "vq._codebook." in k or not st[k].is_floating_point()]
+    t0 = time.time()
+    O.train_steps(st, [(txt, vol)], cfg, lr=1.25e-5, max_grad_norm=0.5, frozen=frozen)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 pair, 1 full train step (fwd+bwd+clip+Adam) at 480x480x240 fp32, L={L}, {dt:.1f} s on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CTCLIP_BENCH_BATCH", 16)), help="pairs per GPU")
+    ap.add_argument("--text-len", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--local-negatives", action="store_true", help="BASELINE config 3: no embedding all-gather")
+    ap.add_argument("--small", action="store_true", help="debug: 2+2-layer model on 64^3 volumes")
+    args = ap.parse_args()
+
+    from utils.CTClipTrainer import CTClipTrainer
+    from ctclip_hip.lib import hip
+
+    vit_cfg, text_cfg, depth, size = dict(VIT), dict(TEXT), 240, 480
+    if args.small:
+        vit_cfg.update(image_size=64, patch_size=16, temporal_patch_size=16, spatial_depth=2, temporal_depth=2,
+                       codebook_size=512)
+        text_cfg.update(num_hidden_layers=2)
+        depth, size = 64, 64
+    model = build_model(vit_cfg, text_cfg)
+    model.gather_negatives = not args.local_negatives
+    trainer = CTClipTrainer(model, batch_size=args.batch, results_folder=None)
+    rt = trainer.accelerator
+    world, rank, dev = rt.num_processes, rt.process_index, rt.device
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    vol, txt = synthetic_batch(args.batch, depth, size, args.text_len, text_cfg["vocab_size"], dev, rank)
+    batch = (vol, txt)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = trainer.train_step(batch)
+    # dominant kernel: the bf16 MFMA GEMM family.  algorithmic work of a launch = 2*M*N*K.
+    hip.time_kernel("gemm_bf16", lambda A, B, C, bias, resid, M, N, K, *rest: 2.0 * M * N * K)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    timing = hip.stop_timing()["ctclip_gemm_bf16"]
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
+
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        gemm_tflops = timing["work"] / (timing["total_ms"] * 1e-3) / 1e12 if timing["total_ms"] > 0 else 0.0
+        out = {
+            "metric": "CT-volume-report pairs/sec (480x480x240 bf16)", "value": pairs / dt, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("debug-small" if args.small else
+                                    "BASELINE configs[1]: CT-ViT base (512d, 4+4 layers, 8x32 heads, cb 8192) + BERT-base-shape "
+                                    "text encoder, 480x480x240 bf16 volumes, 128-token reports, full train_step"),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "text_len": args.text_len,
+                       "negatives": "local" if args.local_negatives or world == 1 else "global (all-gather)",
+                       "parallelism": f"dp{world}", "peak_hbm_gib": round(peak_mem, 1), "final_loss": float(loss)},
+            "roofline": {"kernel": "gemm_bf16_kernel (all operand layouts)", "bound": "mfma", "achieved": gemm_tflops,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_BF16_TFLOPS,
+                         "traffic": None, "launches_per_step": timing["launches"] / args.steps,
+                         "gemm_ms_per_step": timing["total_ms"] / args.steps},
+        }
+        if not args.no_cpu_baseline and world == 1 and not args.small:
+            out["cpu_baseline"] = cpu_baseline(model, depth, size, args.text_len, text_cfg["vocab_size"])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

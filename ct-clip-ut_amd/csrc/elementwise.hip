@@ -242,3 +242,51 @@ int ctclip_add_f32(const float* a, const float* b, float* y, void* y_bf16, long 
 }
 
 }  // extern "C"
+
+// ---- BERT embeddings: out[r,:] = word[ids[r]] + pos[r % L] + type[tt[r]]  (transformers BertEmbeddings) ----
+namespace {
+__global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const long* __restrict__ ids, const long* __restrict__ tt,
+                                                             const float* __restrict__ word, const float* __restrict__ pos,
+                                                             const float* __restrict__ type, float* __restrict__ out,
+                                                             long rows, int L, int H4) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * H4; e += (long)gridDim.x * 256) {
+    const long r = e / H4;
+    const int c = (int)(e % H4);
+    const float4 a = ((const float4*)word)[ids[r] * H4 + c];
+    const float4 b = ((const float4*)pos)[(r % L) * H4 + c];
+    const float4 d = ((const float4*)type)[(tt ? tt[r] : 0) * H4 + c];
+    ((float4*)out)[e] = make_float4(a.x + b.x + d.x, a.y + b.y + d.y, a.z + b.z + d.z, a.w + b.w + d.w);
+  }
+}
+__global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const long* __restrict__ ids, const long* __restrict__ tt,
+                                                             const float* __restrict__ dy, float* __restrict__ dword,
+                                                             float* __restrict__ dpos, float* __restrict__ dtype_,
+                                                             long rows, int L, int H) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * H; e += (long)gridDim.x * 256) {
+    const long r = e / H;
+    const int c = (int)(e % H);
+    const float g = dy[e];
+    atomicAdd(dword + ids[r] * H + c, g);
+    atomicAdd(dpos + (r % L) * H + c, g);
+    atomicAdd(dtype_ + (tt ? tt[r] : 0) * H + c, g);
+  }
+}
+}  // namespace
+
+extern "C" {
+int ctclip_bert_embed_fwd(const long* ids, const long* token_type, const float* word, const float* pos, const float* type,
+                          float* out, long rows, int L, int hidden, void* stream) {
+  if (rows <= 0) return 0;
+  if (hidden & 3) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(bert_embed_fwd_kernel, dim3(grid_for(rows * (hidden / 4))), dim3(256), 0, (hipStream_t)stream, ids,
+                     token_type, word, pos, type, out, rows, L, hidden / 4);
+  CTCLIP_CHECK_LAUNCH();
+}
+int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* dy, float* dword, float* dpos,
+                          float* dtype, long rows, int L, int hidden, void* stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3(grid_for(rows * hidden)), dim3(256), 0, (hipStream_t)stream, ids,
+                     token_type, dy, dword, dpos, dtype, rows, L, hidden);
+  CTCLIP_CHECK_LAUNCH();
+}
+}

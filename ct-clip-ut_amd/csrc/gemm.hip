@@ -160,28 +160,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
   const int half = lane >> 5, lc = lane & 31;
 
   if (EPI == 1) {
-    // arg-max over the M (code) rows of this wave's 64x64 sub-tile, per N (token) column.
-    // part[(col) * n_parts + tm*2 + wm] = (best value, best row index); ties -> lowest row.
+    // top-2 over the M (code) rows of this wave's 64x64 sub-tile, per N (token) column.
+    // part[((col) * n_parts + tm*2 + wm) * 2 + {0,1}] = (value, row index), best first; ties -> lowest row.
+    // Two candidates per 64-code slab let the caller re-rank near-ties in f32 (bf16 scores can flip them).
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = col0 + wn * 64 + j * 32 + lc;
-      float best = -INFINITY;
-      int besti = 0x7fffffff;
+      float b1 = -INFINITY, b2 = -INFINITY;
+      int i1 = 0x7fffffff, i2 = 0x7fffffff;
+      auto push = [&](float v, int row) {
+        if (v > b1 || (v == b1 && row < i1)) { b2 = b1; i2 = i1; b1 = v; i1 = row; }
+        else if (v > b2 || (v == b2 && row < i2)) { b2 = v; i2 = row; }
+      };
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row0 + wm * 64 + i * 32 + acc_row(r, half);
-          const float v = acc[i][j][r];
-          if (row < g.M && (v > best || (v == best && row < besti))) { best = v; besti = row; }
+          if (row < g.M) push(acc[i][j][r], row);
         }
-      const float ob = __shfl_xor(best, 32, 64);
-      const int oi = __shfl_xor(besti, 32, 64);
-      if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+      const float o1 = __shfl_xor(b1, 32, 64), o2 = __shfl_xor(b2, 32, 64);
+      const int oi1 = __shfl_xor(i1, 32, 64), oi2 = __shfl_xor(i2, 32, 64);
+      if (oi1 != 0x7fffffff) push(o1, oi1);
+      if (oi2 != 0x7fffffff) push(o2, oi2);
       if (half == 0 && col < g.N) {
-        const long p = (long)col * g.n_parts + tm * 2 + wm;
-        g.part_val[p] = best;
-        g.part_idx[p] = besti;
+        const long p = ((long)col * g.n_parts + tm * 2 + wm) * 2;
+        g.part_val[p] = b1; g.part_idx[p] = i1;
+        g.part_val[p + 1] = b2; g.part_idx[p + 1] = i2;
       }
     }
     return;
@@ -239,11 +244,12 @@ extern "C" {
 // See include/ctclip_hip.h for the contract.
 int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const float* resid,
                      int M, int N, int K, long lda, long ldb, long ldc, long ldr,
-                     int a_kmajor, int b_kmajor, int c_fp32, int split_k, float alpha, int act,
+                     int a_kmajor, int b_kmajor, int c_fp32, int split_k, int accumulate, float alpha, int act,
                      void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (bad_layout(A, lda, a_kmajor ? K : M) || bad_layout(B, ldb, b_kmajor ? K : N)) return (int)hipErrorInvalidValue;
-  if (split_k > 1 && (!c_fp32 || act != 0)) return (int)hipErrorInvalidValue;
+  if (split_k > 1 && !accumulate) return (int)hipErrorInvalidValue;
+  if (accumulate && (!c_fp32 || act != 0)) return (int)hipErrorInvalidValue;
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
@@ -253,12 +259,12 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
   if (split_k > nk) split_k = nk;
   g.ktiles_per_split = (nk + split_k - 1) / split_k;
   g.split_k = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
-  g.c_fp32 = c_fp32; g.atomic_out = (split_k > 1) ? 1 : 0; g.act = act; g.alpha = alpha;
+  g.c_fp32 = c_fp32; g.atomic_out = accumulate ? 1 : 0; g.act = act; g.alpha = alpha;
   return launch<0>(g, a_kmajor, b_kmajor, (hipStream_t)stream);
 }
 
-// scores[m][n] = sum_k A[m][k] B[n][k]; for every column n writes the arg-max over the rows of each
-// 64-row slab: part_val/part_idx are [N][n_parts], n_parts = 2*ceil(M/128).
+// scores[m][n] = sum_k A[m][k] B[n][k]; for every column n writes the top-2 over the rows of each
+// 64-row slab: part_val/part_idx are [N][n_parts][2], n_parts = 2*ceil(M/128) (index 0x7fffffff = empty).
 int ctclip_gemm_argmax_partial(const void* A, const void* B, float* part_val, int* part_idx,
                                int M, int N, int K, long lda, long ldb, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;

@@ -21,7 +21,7 @@ __device__ __forceinline__ void fma4(float4& a, const float4& w, const float4& x
 // y = x + bias + conv(x)                 out[t] uses x[t + kt - 2], x[h + kh - 1], x[w + kw - 1]
 __global__ __launch_bounds__(256) void peg_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w27,
                                                       const float* __restrict__ bias, float* __restrict__ y,
-                                                      bf16_t* __restrict__ y16, Grid5 g) {
+                                                      bf16_t* __restrict__ y16, Grid5 g, int residual) {
   const long total = g.B * g.T * g.H * g.W * g.d4;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int c = (int)(idx % g.d4);
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void peg_fwd_kernel(const float* __restrict__ 
     const int h_ = (int)((pos / g.W) % g.H);
     const int t_ = (int)((pos / ((long)g.W * g.H)) % g.T);
     const long b = pos / ((long)g.W * g.H * g.T);
-    float4 acc = ((const float4*)x)[idx];
+    float4 acc = residual ? ((const float4*)x)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 bv = ((const float4*)bias)[c];
     acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
 #pragma unroll
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void peg_fwd_kernel(const float* __restrict__ 
 
 // dx = dy + conv^T(dy):  x[pos] fed output (t - kt + 2, h - kh + 1, w - kw + 1) through tap (kt,kh,kw)
 __global__ __launch_bounds__(256) void peg_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w27,
-                                                           float* __restrict__ dx, bf16_t* __restrict__ dx16, Grid5 g) {
+                                                           float* __restrict__ dx, bf16_t* __restrict__ dx16, Grid5 g,
+                                                           int residual) {
   const long total = g.B * g.T * g.H * g.W * g.d4;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int c = (int)(idx % g.d4);
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void peg_bwd_data_kernel(const float* __restri
     const int h_ = (int)((pos / g.W) % g.H);
     const int t_ = (int)((pos / ((long)g.W * g.H)) % g.T);
     const long b = pos / ((long)g.W * g.H * g.T);
-    float4 acc = ((const float4*)dy)[idx];
+    float4 acc = residual ? ((const float4*)dy)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
       const int tt = t_ - kt + 2;
@@ -159,22 +160,22 @@ inline unsigned grid_for(long work) {
 extern "C" {
 
 int ctclip_peg_fwd(const float* x, const float* w27, const float* bias, float* y, void* y_bf16, long B, int T, int H,
-                   int W, int d, void* stream) {
+                   int W, int d, int residual, void* stream) {
   if (B * T * H * W <= 0) return 0;
   if (d & 3) return (int)hipErrorInvalidValue;
   Grid5 g{B, T, H, W, d / 4};
   hipLaunchKernelGGL(peg_fwd_kernel, dim3(grid_for(B * T * H * W * g.d4)), dim3(256), 0, (hipStream_t)stream, x, w27,
-                     bias, y, (bf16_t*)y_bf16, g);
+                     bias, y, (bf16_t*)y_bf16, g, residual);
   CTCLIP_CHECK_LAUNCH();
 }
 
 int ctclip_peg_bwd_data(const float* dy, const float* w27, float* dx, void* dx_bf16, long B, int T, int H, int W, int d,
-                        void* stream) {
+                        int residual, void* stream) {
   if (B * T * H * W <= 0) return 0;
   if (d & 3) return (int)hipErrorInvalidValue;
   Grid5 g{B, T, H, W, d / 4};
   hipLaunchKernelGGL(peg_bwd_data_kernel, dim3(grid_for(B * T * H * W * g.d4)), dim3(256), 0, (hipStream_t)stream, dy,
-                     w27, dx, (bf16_t*)dx_bf16, g);
+                     w27, dx, (bf16_t*)dx_bf16, g, residual);
   CTCLIP_CHECK_LAUNCH();
 }
 

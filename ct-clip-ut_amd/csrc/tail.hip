@@ -1,0 +1,273 @@
+// Small f32 pieces of the step that must not lose precision: a generic f32 GEMM (position-bias MLP,
+// latent projections, logits), the symmetric InfoNCE loss, relative-position bias expansion, and the
+// fused grad-clip + Adam update.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// f32 GEMM, 64x64x16 tiles, 256 threads x (4x4) outputs.  Same operand-layout flags as the bf16 GEMM.
+// act: 0 none, 2 leaky_relu(slope), 3 multiply by leaky_relu'(aux) (backward of act 2).
+// ------------------------------------------------------------------------------------------------
+struct SGemm {
+  const float* A; const float* B; float* C; const float* bias; const float* aux; const float* alpha_dev;
+  long lda, ldb, ldc, ldaux;
+  int M, N, K, a_kmajor, b_kmajor, act, accumulate, alpha_exp;
+  float alpha, slope;
+};
+
+__global__ __launch_bounds__(256) void sgemm_kernel(SGemm g) {
+  __shared__ float As[16][65], Bs[16][65];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    for (int e = tid; e < 64 * 16; e += 256) {
+      int r, k;
+      if (g.a_kmajor) { r = e >> 4; k = e & 15; } else { k = e >> 6; r = e & 63; }
+      float v = 0.f;
+      if (row0 + r < g.M && k0 + k < g.K)
+        v = g.a_kmajor ? g.A[(long)(row0 + r) * g.lda + k0 + k] : g.A[(long)(k0 + k) * g.lda + row0 + r];
+      As[k][r] = v;
+      if (g.b_kmajor) { r = e >> 4; k = e & 15; } else { k = e >> 6; r = e & 63; }
+      v = 0.f;
+      if (col0 + r < g.N && k0 + k < g.K)
+        v = g.b_kmajor ? g.B[(long)(col0 + r) * g.ldb + k0 + k] : g.B[(long)(k0 + k) * g.ldb + col0 + r];
+      Bs[k][r] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[k][ty * 4 + i]; b[i] = Bs[k][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    }
+    __syncthreads();
+  }
+  float alpha = g.alpha;
+  if (g.alpha_dev) alpha *= g.alpha_exp ? __expf(*g.alpha_dev) : *g.alpha_dev;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = row0 + ty * 4 + i, c = col0 + tx * 4 + j;
+      if (r >= g.M || c >= g.N) continue;
+      float v = acc[i][j] * alpha + (g.bias ? g.bias[c] : 0.f);
+      if (g.act == 2) v = v > 0.f ? v : v * g.slope;
+      if (g.act == 3) v *= (g.aux[(long)r * g.ldaux + c] > 0.f) ? 1.f : g.slope;
+      float* dst = g.C + (long)r * g.ldc + c;
+      *dst = g.accumulate ? (*dst + v) : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// symmetric InfoNCE (CTClipTrainer.py:164-175 with targets = arange): one workgroup, G <= 4096
+// loss = 0.5 * (mean_i (lse_row_i - s_ii) + mean_j (lse_col_j - s_jj)); dsim = dloss/dsim
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void infonce_kernel(const float* __restrict__ sim, float* __restrict__ loss,
+                                                       float* __restrict__ dsim, int G, float* __restrict__ ws) {
+  float* row_lse = ws;       // [G]
+  float* col_lse = ws + G;   // [G]
+  __shared__ float red[32];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < G; i += nt) {
+    float m = -INFINITY, mc = -INFINITY;
+    for (int j = 0; j < G; ++j) { m = fmaxf(m, sim[(long)i * G + j]); mc = fmaxf(mc, sim[(long)j * G + i]); }
+    float s = 0.f, sc = 0.f;
+    for (int j = 0; j < G; ++j) { s += expf(sim[(long)i * G + j] - m); sc += expf(sim[(long)j * G + i] - mc); }
+    row_lse[i] = m + logf(s);
+    col_lse[i] = mc + logf(sc);
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int i = tid; i < G; i += nt) part += (row_lse[i] - sim[(long)i * G + i]) + (col_lse[i] - sim[(long)i * G + i]);
+  part = wave_sum(part);
+  if ((tid & 63) == 0) red[tid >> 6] = part;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (nt + 63) / 64; ++w) t += red[w];
+    *loss = 0.5f * t / (float)G;
+  }
+  const float k = 0.5f / (float)G;
+  for (long e = tid; e < (long)G * G; e += nt) {
+    const int i = (int)(e / G), j = (int)(e % G);
+    const float s = sim[e];
+    dsim[e] = k * (expf(s - row_lse[i]) + expf(s - col_lse[j]) - (i == j ? 2.f : 0.f));
+  }
+}
+
+// bias[h][i][j] = table[relidx[i][j]][h]    (table is the [R, heads] output of the position MLP)
+__global__ __launch_bounds__(256) void bias_expand_kernel(const float* __restrict__ table, const uint16_t* __restrict__ relidx,
+                                                          float* __restrict__ bias, int heads, long nn) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nn * heads; e += (long)gridDim.x * 256) {
+    const int h = (int)(e / nn);
+    const long ij = e % nn;
+    bias[e] = table[(long)relidx[ij] * heads + h];
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_by_dev_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                           float* __restrict__ y, long n) {
+  const float k = *s;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) y[e] = x[e] * k;
+}
+
+// out += sum(a * b)   (d temperature = sum(dsim * sim), CTCLIP tail backward)
+__global__ __launch_bounds__(256) void dot_accum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ out, long n) {
+  float s = 0.f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) s += a[e] * b[e];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimiser: global grad-norm + clip + Adam/AdamW in one pass over flat f32 arenas
+// (CTClipTrainer.py:199-202, optimizer.py:42-54).  The clip coefficient is computed on device from the
+// squared norm so the host never synchronises.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, long n, float* __restrict__ out) {
+  float s = 0.f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+    const float4 v = ((const float4*)g)[e];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0)
+    for (long e = n4 * 4 + threadIdx.x; e < n; e += 256) s += g[e] * g[e];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v; bf16_t* p16;
+  long n;
+  float lr, b1, b2, eps, wd, bc1, bc2_sqrt, max_norm;
+  int decoupled;
+  const float* gnorm_sq;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  float coef = 1.f;
+  if (a.gnorm_sq && a.max_norm > 0.f) coef = fminf(1.f, a.max_norm / (sqrtf(*a.gnorm_sq) + 1e-6f));
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.n; e += (long)gridDim.x * 256) {
+    float p = a.p[e], g = a.g[e] * coef;
+    if (a.wd != 0.f) {
+      if (a.decoupled) p *= (1.f - a.lr * a.wd);
+      else g += a.wd * p;
+    }
+    const float m = a.b1 * a.m[e] + (1.f - a.b1) * g;
+    const float v = a.b2 * a.v[e] + (1.f - a.b2) * g * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p -= (a.lr / a.bc1) * (m / denom);
+    a.p[e] = p; a.m[e] = m; a.v[e] = v;
+    if (a.p16) a.p16[e] = f32_to_bf16(p);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long rows, int cols, long ld,
+                                                     float* __restrict__ out, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  float s = 0.f;
+  for (long r = r0; r < r1; ++r) {
+    if (sizeof(T) == 2) s += bf16_to_f32(((const bf16_t*)x)[r * ld + c]);
+    else s += ((const float*)x)[r * ld + c];
+  }
+  atomicAdd(out + c, s);
+}
+
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ act,
+                                                        float* __restrict__ y, long n, float slope) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256)
+    y[e] = dy[e] * (act[e] > 0.f ? 1.f : slope);
+}
+
+inline unsigned grid_for(long work, long cap = 2048) {
+  long b = (work + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctclip_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* aux, int M, int N, int K,
+                    long lda, long ldb, long ldc, long ldaux, int a_kmajor, int b_kmajor, float alpha,
+                    const float* alpha_dev, int alpha_exp, int act, float slope, int accumulate, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  SGemm g{A, B, C, bias, aux, alpha_dev, lda, ldb, ldc, ldaux, M, N, K, a_kmajor, b_kmajor, act, accumulate, alpha_exp,
+          alpha, slope};
+  hipLaunchKernelGGL(sgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, g);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_infonce(const float* sim, float* loss, float* dsim, int G, float* workspace, void* stream) {
+  if (G <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(infonce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sim, loss, dsim, G, workspace);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_bias_expand(const float* table, const uint16_t* relidx, float* bias, int heads, int n, void* stream) {
+  const long nn = (long)n * n;
+  hipLaunchKernelGGL(bias_expand_kernel, dim3(grid_for(nn * heads)), dim3(256), 0, (hipStream_t)stream, table, relidx,
+                     bias, heads, nn);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_scale_by_dev(const float* x, const float* s, float* y, long n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scale_by_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, s, y, n);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_colsum_accum(const void* x, int x_is_bf16, long rows, int cols, long ld, float* out, void* stream) {
+  if (rows <= 0 || cols <= 0) return 0;
+  const int rpb = 256;
+  dim3 grid((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb));
+  if (x_is_bf16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, cols, ld, out, rpb);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, cols, ld, out, rpb);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_leaky_bwd(const float* dy, const float* act, float* y, long n, float slope, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, act, y, n, slope);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_dot_accum(const float* a, const float* b, float* out, long n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dot_accum_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_sumsq_accum(const float* g, long n, float* out, void* stream) {
+  if (n <= 0) return 0;
+  if (((uintptr_t)g) & 15) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, g, n / 4, n, out);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int decoupled, float bias_corr1, float bias_corr2,
+                     const float* gnorm_sq, float max_norm, void* stream) {
+  if (n <= 0) return 0;
+  AdamArgs a{p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2),
+             max_norm, decoupled, gnorm_sq};
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, (hipStream_t)stream, a);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+}  // extern "C"

@@ -47,6 +47,25 @@ class _Hip:
         self._dll = None
         self._protos = None
         self._fns = {}
+        self._timed = {}        # kernel name -> list of (start_event, end_event, work) while timing is on
+
+    # -- optional per-launch HIP-event timing (bench.py roofline): events are recorded on the launch stream ----
+    def time_kernel(self, name, work_fn):
+        """Record a HIP event pair around every `name` launch; work_fn(*args) -> algorithmic work of that launch."""
+        full = name if name.startswith("ctclip_") else "ctclip_" + name
+        self._timed[full] = {"work_fn": work_fn, "events": []}
+        self._fns.pop(name, None)
+        self._fns.pop(full, None)
+
+    def stop_timing(self):
+        out = {}
+        for k, v in self._timed.items():
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b, _ in v["events"]]
+            out[k] = {"launches": len(ms), "total_ms": float(sum(ms)), "work": float(sum(w for _, _, w in v["events"]))}
+        self._timed = {}
+        self._fns = {}
+        return out
 
     def _ensure(self):
         if self._dll is not None:
@@ -97,7 +116,15 @@ class _Hip:
                         conv.append(int(a))
                 else:
                     conv.append(a)
-            err = cfn(*conv)
+            timed = self._timed.get(full)
+            if timed is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                err = cfn(*conv)
+                e1.record()
+                timed["events"].append((e0, e1, timed["work_fn"](*args)))
+            else:
+                err = cfn(*conv)
             if err != 0:
                 raise RuntimeError(f"{full} failed with hipError_t {err}")
 

@@ -1,0 +1,616 @@
+"""Autograd functions over libctclip_hip.so.
+
+Every forward/backward here is a sequence of C-ABI kernel launches on torch's current HIP stream; torch
+supplies device memory, the autograd graph and (for one-off weight re-layouts) tensor plumbing.  There
+is no eager/CPU fallback: CPU tensors raise inside `hip.*`.
+
+Numerics contract: MFMA operands are bf16, accumulation / residual stream / LayerNorm /
+softmax statistics / losses / optimiser are f32.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.autograd import Function
+
+from .lib import hip
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+_weight_epoch = 0
+
+
+def bump_weight_epoch() -> None:
+    """Call after parameters were updated through raw pointers (the fused optimiser does)."""
+    global _weight_epoch
+    _weight_epoch += 1
+
+
+class ShadowCache:
+    """Per-module cache of kernel-layout copies of parameters (bf16, padded, re-ordered).
+
+    Rebuilt lazily when any source parameter's version counter, storage or the global weight epoch changes."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, key, params, builder):
+        ver = (_weight_epoch,) + tuple((p._version, p.data_ptr()) for p in params)
+        ent = self._store.get(key)
+        if ent is None or ent[0] != ver:
+            with torch.no_grad():
+                ent = (ver, builder())
+            self._store[key] = ent
+        return ent[1]
+
+
+def pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def head_pad(dh: int) -> int:
+    if dh <= 32:
+        return 32
+    if dh <= 64:
+        return 64
+    raise ValueError(f"dim_head {dh} > 64 is not supported by the gfx950 attention kernel")
+
+
+def pad_head_rows(w: torch.Tensor, heads: int, dh: int, dp: int) -> torch.Tensor:
+    """[heads*dh, K] -> [heads*dp, K] with zero rows inserted per head."""
+    if dh == dp:
+        return w
+    out = w.new_zeros(heads, dp, w.shape[1])
+    out[:, :dh] = w.reshape(heads, dh, -1)
+    return out.reshape(heads * dp, -1)
+
+
+def unpad_head_rows(w: torch.Tensor, heads: int, dh: int, dp: int) -> torch.Tensor:
+    if dh == dp:
+        return w
+    return w.reshape(heads, dp, -1)[:, :dh].reshape(heads * dh, -1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# thin kernel wrappers
+# ---------------------------------------------------------------------------------------------------
+
+def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_dtype=BF16, bias=None, resid=None,
+         split_k=1, accumulate=False, alpha=1.0, act=0):
+    """C[M,N] = opA(A) opB(B) on MFMA; A,B are 2-D bf16 (row stride taken from the tensors)."""
+    if out is None:
+        out = (torch.zeros if accumulate else torch.empty)(M, N, dtype=out_dtype, device=A.device)
+    hip.gemm_bf16(A, B, out, bias, resid, M, N, K, A.stride(0), B.stride(0), out.stride(0),
+                  0 if resid is None else resid.stride(0), int(a_kmajor), int(b_kmajor),
+                  int(out.dtype == F32), split_k, int(accumulate), float(alpha), act)
+    return out
+
+
+def _splits_for(m_out: int, n_out: int, k: int) -> int:
+    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    nk = (k + 63) // 64
+    return max(1, min(nk, (1024 + tiles - 1) // tiles))
+
+
+def wgrad(dy16, x16, n_feat, k_feat, tokens, out=None):
+    """dW[n_feat,k_feat] (+)= dy^T x over `tokens` rows; f32 atomics (out must be zero or a running sum)."""
+    if out is None:
+        out = torch.zeros(n_feat, k_feat, dtype=F32, device=dy16.device)
+    hip.gemm_bf16(dy16, x16, out, None, None, n_feat, k_feat, tokens, dy16.stride(0), x16.stride(0), out.stride(0), 0,
+                  0, 0, 1, _splits_for(n_feat, k_feat, tokens), 1, 1.0, 0)
+    return out
+
+def colsum(x2d, out=None):
+    """out[c] (+)= sum_r x[r, c]  (bias gradients); x f32 or bf16."""
+    rows, cols = x2d.shape
+    if out is None:
+        out = torch.zeros(cols, dtype=F32, device=x2d.device)
+    hip.colsum_accum(x2d, int(x2d.dtype == BF16), rows, cols, x2d.stride(0), out)
+    return out
+
+
+def dgrad(dy16, w16, tokens, n_feat, k_feat, *, out_dtype=F32, resid=None):
+    """dx[tokens,k_feat] = dy[tokens,n_feat] W[n_feat,k_feat]."""
+    return gemm(dy16, w16, tokens, k_feat, n_feat, a_kmajor=True, b_kmajor=False, out_dtype=out_dtype, resid=resid)
+
+
+def layernorm(x2d, gamma, beta, eps, want16=True, want32=False):
+    rows, dim = x2d.shape
+    y16 = torch.empty(rows, dim, dtype=BF16, device=x2d.device) if want16 else None
+    y32 = torch.empty(rows, dim, dtype=F32, device=x2d.device) if want32 else None
+    mean = torch.empty(rows, dtype=F32, device=x2d.device)
+    rstd = torch.empty(rows, dtype=F32, device=x2d.device)
+    hip.layernorm_fwd(x2d, gamma, beta, y16, y32, mean, rstd, rows, dim, float(eps))
+    return y16, y32, mean, rstd
+
+
+def cast16(x):
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    hip.cast_f32_bf16(x, y, x.numel())
+    return y
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
+# LayerNorm as a module-level op (Transformer.norm_out, patch-embed tail)
+# ---------------------------------------------------------------------------------------------------
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        shape = x.shape
+        x2 = _c(x).reshape(-1, shape[-1])
+        _, y, mean, rstd = layernorm(x2, gamma, beta, eps, want16=False, want32=True)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.has_beta = beta is not None
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        dy2 = _c(dy).reshape(x2.shape)
+        dx = torch.empty_like(x2)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma) if ctx.has_beta else None
+        hip.layernorm_bwd(dy2, x2, gamma, mean, rstd, None, dx, None, dg, db, x2.shape[0], x2.shape[1])
+        return dx.reshape(dy.shape), dg, db, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# PEG
+# ---------------------------------------------------------------------------------------------------
+class PegFn(Function):
+    """attention.py:55-83 (+ the residual of :325 when `residual`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, shape, residual):
+        b, t, h, w = (int(s) for s in shape)
+        d = x.shape[-1]
+        xc = _c(x)
+        w27 = weight.detach().reshape(d, 27).t().contiguous()
+        y = torch.empty_like(xc)
+        hip.peg_fwd(xc, w27, bias.detach(), y, None, b, t, h, w, d, int(residual))
+        ctx.save_for_backward(xc, w27)
+        ctx.geom = (b, t, h, w, d, int(residual))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, w27 = ctx.saved_tensors
+        b, t, h, w, d, residual = ctx.geom
+        dyc = _c(dy)
+        dx = torch.empty_like(dyc)
+        hip.peg_bwd_data(dyc, w27, dx, None, b, t, h, w, d, residual)
+        dw27 = torch.zeros(27, d, dtype=F32, device=dy.device)
+        db = torch.zeros(d, dtype=F32, device=dy.device)
+        hip.peg_bwd_weight(dyc, xc, dw27, db, b, t, h, w, d)
+        return dx, dw27.t().reshape(d, 1, 3, 3, 3), db, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# Attention block: LN -> q / kv projections -> cosine-sim attention -> out projection (+ residual)
+# ---------------------------------------------------------------------------------------------------
+class AttentionFn(Function):
+    """attention.py:126-182 for self-attention without null-kv / mask / causal (the CT-ViT configuration).
+
+    bias_t is the autograd-visible bias input: None, a dense [heads,n,n] tensor, or (table mode) the
+    [R, heads] position table whose dense expansion / index map come in `aux`."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, wq, wkv, q_scale, k_scale, wout, bias_t, sh, cfg, aux):
+        heads, dh, dp, scale, residual, want_probs = cfg
+        nseq, n, dim = x.shape
+        M = nseq * n
+        inner = heads * dp
+        x2 = _c(x).reshape(M, dim)
+        n1, _, mean, rstd = layernorm(x2, gamma.detach(), None, 1e-5)
+        xb = cast16(x2)
+        q = gemm(n1, sh["wq"], M, inner, dim)
+        kv = gemm(xb, sh["wkv"], M, 2 * inner, dim)               # QUIRK attention.py:138: kv from un-normalised x
+        qh = torch.empty_like(q)
+        kh = torch.empty(M, inner, dtype=BF16, device=x.device)
+        qinv = torch.empty(M, heads, dtype=F32, device=x.device)
+        kinv = torch.empty(M, heads, dtype=F32, device=x.device)
+        hip.headnorm_fwd(q, sh["q_scale"], qh, qinv, M, heads, dp, inner, inner, float(scale))
+        hip.headnorm_fwd(kv, sh["k_scale"], kh, kinv, M, heads, dp, 2 * inner, inner, 1.0)
+        o = torch.empty(M, inner, dtype=BF16, device=x.device)
+        lse = torch.empty(nseq, heads, n, dtype=F32, device=x.device)
+        kind = aux["kind"]                                        # None | "dense" | "table"
+        bias_dense = None
+        if kind == "dense":
+            bias_dense = _c(bias_t.detach().to(F32))
+        elif kind == "table":
+            bias_dense = aux["dense"]
+        hip.attn_fwd(qh, kh, kv[:, inner:], o, lse, bias_dense, None, nseq, n, heads, dp, inner, inner, 2 * inner,
+                     inner, 1.0)
+        y = gemm(o, sh["wout"], M, dim, inner, out_dtype=F32, resid=x2 if residual else None)
+        if want_probs:
+            probs = torch.empty(nseq, heads, n, n, dtype=F32, device=x.device)
+            hip.attn_probs(qh, kh, lse, bias_dense, None, probs, nseq, n, heads, dp, inner, inner, 1.0)
+        else:
+            probs = x.new_empty(0)
+        ctx.save_for_backward(x2, gamma, mean, rstd, n1, xb, q, kv, qh, kh, qinv, kinv, o, lse,
+                              bias_dense if bias_dense is not None else x2.new_empty(0))
+        ctx.sh, ctx.cfg, ctx.aux, ctx.shape = sh, cfg, aux, (nseq, n, dim)
+        ctx.mark_non_differentiable(probs)
+        return y.reshape(nseq, n, dim), probs
+
+    @staticmethod
+    def backward(ctx, dy, _dprobs):
+        x2, gamma, mean, rstd, n1, xb, q, kv, qh, kh, qinv, kinv, o, lse, bias_dense = ctx.saved_tensors
+        sh, aux = ctx.sh, ctx.aux
+        heads, dh, dp, scale, residual, _ = ctx.cfg
+        nseq, n, dim = ctx.shape
+        M, inner = nseq * n, heads * dp
+        dev = dy.device
+        kind = aux["kind"]
+        if bias_dense.numel() == 0:
+            bias_dense = None
+        dy2 = _c(dy).reshape(M, dim)
+        dyb = cast16(dy2)
+        do = dgrad(dyb, sh["wout"], M, dim, inner, out_dtype=BF16)
+        dwout = wgrad(dyb, o, dim, inner, M)
+        dqh = torch.empty(M, inner, dtype=BF16, device=dev)
+        dkh = torch.empty(M, inner, dtype=BF16, device=dev)
+        dkv = torch.empty(M, 2 * inner, dtype=BF16, device=dev)
+        delta = torch.empty(nseq, heads, n, dtype=F32, device=dev)
+        dbias_dense = dtable = rel = None
+        tsize = 0
+        if kind == "dense" and ctx.needs_input_grad[7]:
+            dbias_dense = torch.zeros(heads, n, n, dtype=F32, device=dev)
+        elif kind == "table":
+            tsize = aux["rows"]
+            dtable = torch.zeros(heads, tsize, dtype=F32, device=dev)
+            rel = aux["relidx"]
+        hip.attn_bwd(qh, kh, kv[:, inner:], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, None,
+                     dbias_dense, rel, dtable, tsize, nseq, n, heads, dp,
+                     inner, inner, 2 * inner, inner, inner, inner, inner, 2 * inner, 1.0)
+        dq = torch.empty(M, inner, dtype=BF16, device=dev)
+        dqs = torch.zeros(dp, dtype=F32, device=dev)
+        dks = torch.zeros(dp, dtype=F32, device=dev)
+        hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, dqs, M, heads, dp, inner, inner, inner, float(scale))
+        hip.headnorm_bwd(dkh, kv, kinv, sh["k_scale"], dkv, dks, M, heads, dp, inner, 2 * inner, 2 * inner, 1.0)
+        dn1 = dgrad(dq, sh["wq"], M, inner, dim)
+        dwq = wgrad(dq, n1, inner, dim, M)
+        dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None)
+        dwkv = wgrad(dkv, xb, 2 * inner, dim, M)
+        dx = torch.empty(M, dim, dtype=F32, device=dev)
+        dgamma = torch.zeros_like(gamma)
+        hip.layernorm_bwd(dn1, x2, gamma, mean, rstd, dxkv, dx, None, dgamma, None, M, dim)
+        dwq = unpad_head_rows(dwq, heads, dh, dp)
+        dwk = unpad_head_rows(dwkv[:inner], heads, dh, dp)
+        dwv = unpad_head_rows(dwkv[inner:], heads, dh, dp)
+        dwout = unpad_head_rows(dwout.t(), heads, dh, dp).t()
+        dbias = None
+        if kind == "dense":
+            dbias = dbias_dense
+        elif kind == "table":
+            dbias = dtable.t().contiguous()          # [R, heads] like the MLP output
+        return (dx.reshape(nseq, n, dim), dgamma, dwq, torch.cat((dwk, dwv), 0), dqs[:dh], dks[:dh], dwout, dbias,
+                None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------------
+# GEGLU feed-forward: LN -> Linear(dim, 2I) -> GEGLU -> Linear(I, dim) (+ residual)   attention.py:38-51
+# ---------------------------------------------------------------------------------------------------
+class FeedForwardFn(Function):
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, w2, sh, residual):
+        shape = x.shape
+        dim = shape[-1]
+        x2 = _c(x).reshape(-1, dim)
+        M = x2.shape[0]
+        I, Ip = sh["inner"], sh["inner_p"]
+        n2, _, mean, rstd = layernorm(x2, ln_w.detach(), ln_b.detach(), 1e-5)
+        h = gemm(n2, sh["w1"], M, 2 * Ip, dim)
+        g = torch.empty(M, Ip, dtype=BF16, device=x.device)
+        hip.geglu_fwd(h, g, M, Ip, 2 * Ip, Ip)
+        y = gemm(g, sh["w2"], M, dim, Ip, out_dtype=F32, resid=x2 if residual else None)
+        ctx.save_for_backward(x2, ln_w, mean, rstd, n2, h, g)
+        ctx.sh, ctx.residual = sh, residual
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, ln_w, mean, rstd, n2, h, g = ctx.saved_tensors
+        sh = ctx.sh
+        M, dim = x2.shape
+        I, Ip = sh["inner"], sh["inner_p"]
+        dy2 = _c(dy).reshape(M, dim)
+        dyb = cast16(dy2)
+        dg = dgrad(dyb, sh["w2"], M, dim, Ip, out_dtype=BF16)
+        dw2p = wgrad(dyb, g, dim, Ip, M)
+        dh = torch.empty_like(h)
+        hip.geglu_bwd(dg, h, dh, M, Ip, Ip, 2 * Ip)
+        dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim)
+        dw1p = wgrad(dh, n2, 2 * Ip, dim, M)
+        dx = torch.empty(M, dim, dtype=F32, device=dy.device)
+        dlw = torch.zeros_like(ln_w)
+        dlb = torch.zeros_like(ln_w)
+        hip.layernorm_bwd(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, dx, None, dlw, dlb, M, dim)
+        dw1 = torch.cat((dw1p[:I], dw1p[Ip:Ip + I]), 0)
+        dw2 = dw2p[:, :I].contiguous()
+        return dx.reshape(dy.shape), dlw, dlb, dw1, dw2, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# f32 linear (tiny matrices where bf16 would cost parity: position MLP, text latent projection)
+# ---------------------------------------------------------------------------------------------------
+def sgemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, bias=None, act=0, aux=None, alpha=1.0, alpha_dev=None,
+          alpha_exp=False, out=None, accumulate=False, slope=0.1):
+    if out is None:
+        out = torch.empty(M, N, dtype=F32, device=A.device)
+    hip.gemm_f32(A, B, out, bias, aux, M, N, K, A.stride(0), B.stride(0), out.stride(0),
+                 0 if aux is None else aux.stride(0), int(a_kmajor), int(b_kmajor), float(alpha), alpha_dev,
+                 int(alpha_exp), act, float(slope), int(accumulate))
+    return out
+
+
+class LinearF32Fn(Function):
+    """y = act(x W^T + b) in f32; act in {None, 'leaky'} (slope 0.1)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, leaky):
+        x2 = _c(x).reshape(-1, x.shape[-1])
+        M, K = x2.shape
+        N = w.shape[0]
+        y = sgemm(x2, _c(w.detach()), M, N, K, bias=None if b is None else b.detach(), act=2 if leaky else 0)
+        ctx.save_for_backward(x2, w, y)
+        ctx.leaky, ctx.has_b, ctx.xshape = leaky, b is not None, x.shape
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = _c(dy).reshape(M, N)
+        if ctx.leaky:                                    # dy * leaky'(pre-activation); sign(pre) == sign(y)
+            t = torch.empty_like(dy2)
+            hip.leaky_bwd(dy2, y, t, dy2.numel(), 0.1)
+            dy2 = t
+        dx = sgemm(dy2, _c(w.detach()), M, K, N, a_kmajor=True, b_kmajor=False)
+        dw = sgemm(dy2, x2, N, K, M, a_kmajor=False, b_kmajor=False)
+        db = colsum(dy2) if ctx.has_b else None
+        return dx.reshape(ctx.xshape), dw, db, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# patch embedding: gather + LN(F) + Linear(F, dim) + bias + LN(dim)          ctvit.py:44-52
+# ---------------------------------------------------------------------------------------------------
+class PatchEmbedFn(Function):
+    @staticmethod
+    def forward(ctx, volume, ln1w, ln1b, w, b, ln2w, ln2b, sh, geom):
+        patch, tpatch = geom
+        B, C, Dz, Hy, Wx = volume.shape
+        t, h, wt = Dz // tpatch, Hy // patch, Wx // patch
+        F_ = C * tpatch * patch * patch
+        dim = w.shape[0]
+        M = B * t * h * wt
+        vol = _c(volume)
+        is16 = vol.dtype == BF16
+        if not is16 and vol.dtype != F32:
+            raise TypeError("volume must be float32 or bfloat16")
+        ldA = pad8(F_)
+        A = torch.empty(M, ldA, dtype=BF16, device=vol.device)
+        mean1 = torch.empty(M, dtype=F32, device=vol.device)
+        rstd1 = torch.empty(M, dtype=F32, device=vol.device)
+        hip.patch_ln_fwd(vol, int(is16), ln1w.detach(), ln1b.detach(), A, mean1, rstd1, B, C, Dz, Hy, Wx, tpatch, patch,
+                         ldA, 1e-5)
+        z = gemm(A, sh["w"], M, dim, ldA, out_dtype=F32, bias=b.detach())
+        _, y, mean2, rstd2 = layernorm(z, ln2w.detach(), ln2b.detach(), 1e-5, want16=False, want32=True)
+        ctx.save_for_backward(vol, A, mean1, rstd1, z, mean2, rstd2, ln2w)
+        ctx.sh, ctx.geom, ctx.dims = sh, geom, (B, C, Dz, Hy, Wx, F_, ldA, dim, M)
+        return y.reshape(B, t, h, wt, dim)
+
+    @staticmethod
+    def backward(ctx, dy):
+        vol, A, mean1, rstd1, z, mean2, rstd2, ln2w = ctx.saved_tensors
+        sh = ctx.sh
+        patch, tpatch = ctx.geom
+        B, C, Dz, Hy, Wx, F_, ldA, dim, M = ctx.dims
+        dev = dy.device
+        dy2 = _c(dy).reshape(M, dim)
+        dz = torch.empty(M, dim, dtype=F32, device=dev)
+        dzb = torch.empty(M, dim, dtype=BF16, device=dev)
+        d2w = torch.zeros(dim, dtype=F32, device=dev)
+        d2b = torch.zeros(dim, dtype=F32, device=dev)
+        hip.layernorm_bwd(dy2, z, ln2w, mean2, rstd2, None, dz, dzb, d2w, d2b, M, dim)
+        db = colsum(dz)
+        dwp = wgrad(dzb, A, dim, ldA, M)
+        dA = dgrad(dzb, sh["w"], M, dim, ldA, out_dtype=BF16)
+        d1w = torch.zeros(F_, dtype=F32, device=dev)
+        d1b = torch.zeros(F_, dtype=F32, device=dev)
+        hip.patch_ln_bwd(vol, int(vol.dtype == BF16), dA, ldA, mean1, rstd1, d1w, d1b, B, C, Dz, Hy, Wx, tpatch, patch)
+        return None, d1w, d1b, dwp[:, :F_].contiguous(), db, d2w, d2b, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# token re-ordering between the spatial and temporal transformers (ctvit.py:96,99,101)
+# ---------------------------------------------------------------------------------------------------
+class SwapMiddleFn(Function):
+    """[B, A, C, D] -> [B, C, A, D] (contiguous copy on device)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, A, C, D = x.shape
+        out = torch.empty(B, C, A, D, dtype=F32, device=x.device)
+        hip.swap_middle_f32(_c(x), out, B, A, C, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, A, D = dy.shape
+        out = torch.empty(B, A, C, D, dtype=F32, device=dy.device)
+        hip.swap_middle_f32(_c(dy), out, B, C, A, D)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# VQ (cosine-sim codebook, straight-through)            ctvit.py:117-118
+# ---------------------------------------------------------------------------------------------------
+class VQFn(Function):
+    """x [b, n, d] f32 -> (quantised [b,n,d] f32 with straight-through gradient to l2norm(x), indices [b,n])."""
+
+    @staticmethod
+    def forward(ctx, x, embed, embed16, forced_idx=None):
+        b, n, d = x.shape
+        M = b * n
+        x2 = _c(x).reshape(M, d)
+        xn16 = torch.empty(M, d, dtype=BF16, device=x.device)
+        inv = torch.empty(M, dtype=F32, device=x.device)
+        hip.rownorm_fwd(x2, xn16, None, inv, M, d, 1e-12)
+        if forced_idx is not None:                                  # parity-test hook (VectorQuantize.forced_indices)
+            idx = forced_idx.reshape(M).to(x.device, torch.long)
+            quant = embed.index_select(0, idx)
+            ctx.save_for_backward(x2, inv)
+            ctx.mark_non_differentiable(idx)
+            ctx.aux = (x2, inv)
+            return quant.reshape(b, n, d), idx.reshape(b, n)
+        ncodes = embed16.shape[0]
+        ncand = 4 * ((ncodes + 127) // 128)                      # top-2 of every 64-code slab
+        pv = torch.empty(M, ncand, dtype=F32, device=x.device)
+        pi = torch.empty(M, ncand, dtype=torch.int32, device=x.device)
+        hip.gemm_argmax_partial(embed16, xn16, pv, pi, ncodes, M, d, embed16.stride(0), xn16.stride(0))
+        idx = torch.empty(M, dtype=torch.long, device=x.device)
+        quant = torch.empty(M, d, dtype=F32, device=x.device)
+        # 2^-7: twice the worst-case bf16 rounding error of a unit-vector dot product -> exact f32 arg-max
+        hip.vq_select(pv, pi, ncand, x2, inv, _c(embed), idx, quant, M, d, 2.0 ** -7)
+        ctx.save_for_backward(x2, inv)
+        ctx.mark_non_differentiable(idx)
+        ctx.aux = (x2, inv)                                   # for the EMA update by the caller
+        return quant.reshape(b, n, d), idx.reshape(b, n)
+
+    @staticmethod
+    def backward(ctx, dq, _didx):
+        x2, inv = ctx.saved_tensors
+        M, d = x2.shape
+        dx = torch.empty_like(x2)
+        hip.rownorm_bwd(_c(dq).reshape(M, d), x2, inv, dx, M, d)
+        return dx.reshape(dq.shape), None, None, None
+
+
+def vq_ema_update(x2, inv, idx, embed, cluster_size, decay, all_reduce=None):
+    """EMA codebook update of the library's cosine-sim codebook (in place on the buffers)."""
+    ncodes, d = embed.shape[-2], embed.shape[-1]
+    bins = torch.zeros(ncodes, dtype=F32, device=x2.device)
+    esum = torch.zeros(ncodes, d, dtype=F32, device=x2.device)
+    hip.vq_ema_accum(x2, inv, idx.reshape(-1), bins, esum, x2.shape[0], d)
+    if all_reduce is not None:
+        all_reduce(bins)
+        all_reduce(esum)
+    hip.vq_ema_update(embed.reshape(ncodes, d), cluster_size.reshape(ncodes), bins, esum, ncodes, d, float(decay))
+
+
+# ---------------------------------------------------------------------------------------------------
+# CTCLIP tail: mean over depth + visual projection (bf16 MFMA, split-K over 294 912), latent norms, logits, loss
+# ---------------------------------------------------------------------------------------------------
+class VisualLatentFn(Function):
+    """image_tokens [B,T,H,W,D] -> mean over T -> [B, H*W*D] @ W^T   (ctclip.py:111-112,116)."""
+
+    @staticmethod
+    def forward(ctx, tokens, w, w16):
+        B, T = tokens.shape[0], tokens.shape[1]
+        Fdim = tokens[0, 0].numel()
+        a16 = torch.empty(B, Fdim, dtype=BF16, device=tokens.device)
+        hip.mean_mid_fwd(_c(tokens), a16, None, B, T, Fdim)
+        L = w16.shape[0]
+        nk = (Fdim + 63) // 64
+        split = max(1, min(nk, 1024 // max(1, (L + 127) // 128)))
+        out = gemm(a16, w16, B, L, Fdim, out_dtype=F32, split_k=split, accumulate=True)
+        ctx.save_for_backward(a16, w16)
+        ctx.w, ctx.shape = w, tokens.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        a16, w16 = ctx.saved_tensors
+        B, Fdim = a16.shape
+        L = w16.shape[0]
+        T = ctx.shape[1]
+        dyb = cast16(_c(dy))
+        da = dgrad(dyb, w16, B, L, Fdim)                                   # [B, Fdim] f32
+        dtok = torch.empty(ctx.shape, dtype=F32, device=dy.device)
+        hip.mean_mid_bwd(da, dtok, B, T, Fdim)
+        w = ctx.w
+        if w.grad is not None and w.grad.is_contiguous() and w.grad.dtype == F32:
+            # accumulate the (dim_latent x dim_image) weight gradient straight into the arena-backed .grad
+            gemm(dyb, a16, L, Fdim, B, a_kmajor=False, b_kmajor=False, out=w.grad, accumulate=True)
+            dw = None
+        else:
+            dw = wgrad(dyb, a16, L, Fdim, B)
+        return dtok, dw, None
+
+
+class RowNormFn(Function):
+    """x / |x| per row (ctclip.py:119-120), f32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x2 = _c(x)
+        y = torch.empty_like(x2)
+        inv = torch.empty(x2.shape[0], dtype=F32, device=x.device)
+        hip.rownorm_fwd(x2, None, y, inv, x2.shape[0], x2.shape[1], 0.0)
+        ctx.save_for_backward(x2, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, inv = ctx.saved_tensors
+        dx = torch.empty_like(x2)
+        hip.rownorm_bwd(_c(dy), x2, inv, dx, x2.shape[0], x2.shape[1])
+        return dx
+
+
+class SimMatrixFn(Function):
+    """sim = img @ txt^T * exp(temperature)   (ctclip.py:127), f32."""
+
+    @staticmethod
+    def forward(ctx, img, txt, temperature):
+        img, txt = _c(img), _c(txt)
+        Gi, L = img.shape
+        Gt = txt.shape[0]
+        sim = sgemm(img, txt, Gi, Gt, L, alpha_dev=temperature.detach(), alpha_exp=True)
+        ctx.save_for_backward(img, txt, temperature, sim)
+        return sim
+
+    @staticmethod
+    def backward(ctx, ds):
+        img, txt, temperature, sim = ctx.saved_tensors
+        ds = _c(ds)
+        Gi, L = img.shape
+        Gt = txt.shape[0]
+        t = temperature.detach()
+        dimg = sgemm(ds, txt, Gi, L, Gt, a_kmajor=True, b_kmajor=False, alpha_dev=t, alpha_exp=True)
+        dtxt = sgemm(ds, img, Gt, L, Gi, a_kmajor=False, b_kmajor=False, alpha_dev=t, alpha_exp=True)
+        dtemp = torch.zeros((), dtype=F32, device=ds.device)
+        hip.dot_accum(ds, sim, dtemp, ds.numel())                      # d/dT (s0 e^T) = sim
+        return dimg, dtxt, dtemp
+
+
+class InfoNCEFn(Function):
+    """0.5 * (CE(sim, arange) + CE(sim^T, arange))   (CTClipTrainer.py:164-175)."""
+
+    @staticmethod
+    def forward(ctx, sim):
+        sim = _c(sim)
+        G = sim.shape[0]
+        if sim.shape[1] != G:
+            raise ValueError("symmetric InfoNCE needs a square similarity matrix")
+        loss = torch.empty((), dtype=F32, device=sim.device)
+        dsim = torch.empty_like(sim)
+        ws = torch.empty(2 * G, dtype=F32, device=sim.device)
+        hip.infonce(sim, loss, dsim, G, ws)
+        ctx.save_for_backward(dsim)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dsim,) = ctx.saved_tensors
+        out = torch.empty_like(dsim)
+        hip.scale_by_dev(dsim, _c(dloss.to(F32)), out, dsim.numel())
+        return out

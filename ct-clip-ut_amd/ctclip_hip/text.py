@@ -1,0 +1,192 @@
+"""HIP execution of a `transformers.BertModel` text encoder (reference call site src/models/ctclip.py:107).
+
+The reference hands CTCLIP a HuggingFace BertModel (src/train_ctclip.py:17).  CTCLIP keeps that module
+object -- its parameters, names and state-dict keys are untouched -- and, when it recognises the BERT layout,
+runs the encoder through the same gfx950 kernels as CT-ViT: fused QKV GEMM, LDS-staged softmax attention
+with the padding mask (d_head 64), post-LN residual blocks, erf-GELU MLP.
+
+Absolute position embeddings, post-LayerNorm, erf GELU (BertConfig defaults, and CXR-BERT's).  Dropout
+inside the text encoder is not implemented: configs with dropout > 0 raise in train mode.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from .lib import hip
+
+F32 = torch.float32
+BF16 = torch.bfloat16
+
+
+def is_hf_bert(m) -> bool:
+    return all(hasattr(m, a) for a in ("embeddings", "encoder", "config")) and hasattr(m.encoder, "layer") \
+        and hasattr(m.embeddings, "word_embeddings") and hasattr(m.embeddings, "token_type_embeddings")
+
+
+class BertEmbedFn(Function):
+    @staticmethod
+    def forward(ctx, ids, tt, word, pos, type_, lnw, lnb, eps):
+        B, L = ids.shape
+        Hd = word.shape[1]
+        rows = B * L
+        ids_c, tt_c = ids.contiguous(), (tt.contiguous() if tt is not None else None)
+        e = torch.empty(rows, Hd, dtype=F32, device=word.device)
+        hip.bert_embed_fwd(ids_c, tt_c, word.detach(), pos.detach(), type_.detach(), e, rows, L, Hd)
+        _, y, mean, rstd = ops.layernorm(e, lnw.detach(), lnb.detach(), eps, want16=False, want32=True)
+        ctx.save_for_backward(ids_c, tt_c if tt_c is not None else ids_c.new_empty(0), e, mean, rstd, lnw)
+        ctx.dims = (B, L, Hd, word.shape[0], pos.shape[0], type_.shape[0])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, tt, e, mean, rstd, lnw = ctx.saved_tensors
+        B, L, Hd, nw, npos, nt = ctx.dims
+        rows = B * L
+        dev = dy.device
+        de = torch.empty(rows, Hd, dtype=F32, device=dev)
+        dlw, dlb = torch.zeros(Hd, dtype=F32, device=dev), torch.zeros(Hd, dtype=F32, device=dev)
+        hip.layernorm_bwd(ops._c(dy), e, lnw, mean, rstd, None, de, None, dlw, dlb, rows, Hd)
+        dword = torch.zeros(nw, Hd, dtype=F32, device=dev)
+        dpos = torch.zeros(npos, Hd, dtype=F32, device=dev)
+        dtype_ = torch.zeros(nt, Hd, dtype=F32, device=dev)
+        hip.bert_embed_bwd(ids, tt if tt.numel() else None, de, dword, dpos, dtype_, rows, L, Hd)
+        return None, None, dword, dpos, dtype_, dlw, dlb, None
+
+
+class BertLayerFn(Function):
+    """One post-LN encoder layer on x [B*L, H] f32.  p = (qw,qb,kw,kb,vw,vb,aow,aob,l1w,l1b,iw,ib,ow,ob,l2w,l2b)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_add, sh, cfg, *p):
+        B, L, heads, dh, dp, eps = cfg
+        M, Hd = x.shape
+        inner = heads * dp
+        I = sh["inter"]
+        xb = ops.cast16(x)
+        qkv = ops.gemm(xb, sh["wqkv"], M, 3 * inner, Hd, bias=sh["bqkv"])
+        o = torch.empty(M, inner, dtype=BF16, device=x.device)
+        lse = torch.empty(B, heads, L, dtype=F32, device=x.device)
+        scale = 1.0 / math.sqrt(dh)
+        hip.attn_fwd(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, lse, None, mask_add, B, L, heads, dp,
+                     3 * inner, 3 * inner, 3 * inner, inner, scale)
+        a = ops.gemm(o, sh["wao"], M, Hd, inner, out_dtype=F32, bias=p[7].detach(), resid=x)
+        x1_16, x1, mean1, rstd1 = ops.layernorm(a, p[8].detach(), p[9].detach(), eps, want16=True, want32=True)
+        hpre = ops.gemm(x1_16, sh["wi"], M, I, Hd, bias=p[11].detach())
+        m = torch.empty_like(hpre)
+        hip.gelu_fwd(hpre, m, hpre.numel())
+        o2 = ops.gemm(m, sh["wo"], M, Hd, I, out_dtype=F32, bias=p[13].detach(), resid=x1)
+        _, x2, mean2, rstd2 = ops.layernorm(o2, p[14].detach(), p[15].detach(), eps, want16=False, want32=True)
+        ctx.save_for_backward(xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, p[8], p[14],
+                              mask_add if mask_add is not None else x.new_empty(0))
+        ctx.sh, ctx.cfg = sh, cfg
+        return x2
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, l1w, l2w, mask_add = ctx.saved_tensors
+        sh = ctx.sh
+        B, L, heads, dh, dp, eps = ctx.cfg
+        M, Hd = a.shape
+        inner, I = heads * dp, sh["inter"]
+        dev = dy.device
+        if mask_add.numel() == 0:
+            mask_add = None
+        z = lambda n: torch.zeros(n, dtype=F32, device=dev)
+        # output LayerNorm
+        do2 = torch.empty(M, Hd, dtype=F32, device=dev)
+        do2b = torch.empty(M, Hd, dtype=BF16, device=dev)
+        dl2w, dl2b = z(Hd), z(Hd)
+        hip.layernorm_bwd(ops._c(dy), o2, l2w, mean2, rstd2, None, do2, do2b, dl2w, dl2b, M, Hd)
+        dbo = ops.colsum(do2)
+        dm = ops.dgrad(do2b, sh["wo"], M, Hd, I, out_dtype=BF16)
+        dwo = ops.wgrad(do2b, m, Hd, I, M)
+        dh_ = torch.empty_like(hpre)
+        hip.gelu_bwd(dm, hpre, dh_, hpre.numel())
+        dbi = ops.colsum(dh_)
+        dx1 = ops.dgrad(dh_, sh["wi"], M, I, Hd, resid=do2)
+        dwi = ops.wgrad(dh_, x1_16, I, Hd, M)
+        # attention-output LayerNorm
+        da = torch.empty(M, Hd, dtype=F32, device=dev)
+        dab = torch.empty(M, Hd, dtype=BF16, device=dev)
+        dl1w, dl1b = z(Hd), z(Hd)
+        hip.layernorm_bwd(dx1, a, l1w, mean1, rstd1, None, da, dab, dl1w, dl1b, M, Hd)
+        dbao = ops.colsum(da)
+        do = ops.dgrad(dab, sh["wao"], M, Hd, inner, out_dtype=BF16)
+        dwao = ops.wgrad(dab, o, Hd, inner, M)
+        dqkv = torch.empty(M, 3 * inner, dtype=BF16, device=dev)
+        delta = torch.empty(B, heads, L, dtype=F32, device=dev)
+        hip.attn_bwd(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, do, lse, delta, dqkv, dqkv[:, inner:],
+                     dqkv[:, 2 * inner:], None, mask_add, None, None, None, 0, B, L, heads, dp,
+                     3 * inner, 3 * inner, 3 * inner, inner, inner, 3 * inner, 3 * inner, 3 * inner,
+                     1.0 / math.sqrt(dh))
+        dbqkv = ops.colsum(dqkv)
+        dx = ops.dgrad(dqkv, sh["wqkv"], M, 3 * inner, Hd, resid=da)
+        dwqkv = ops.wgrad(dqkv, xb, 3 * inner, Hd, M)
+        un = lambda w: ops.unpad_head_rows(w, heads, dh, dp)
+        unb = lambda b_: ops.unpad_head_rows(b_[:, None], heads, dh, dp)[:, 0]
+        grads = (un(dwqkv[:inner]), unb(dbqkv[:inner]), un(dwqkv[inner:2 * inner]), unb(dbqkv[inner:2 * inner]),
+                 un(dwqkv[2 * inner:]), unb(dbqkv[2 * inner:]), un(dwao.t()).t(), dbao, dl1w, dl1b, dwi, dbi, dwo, dbo,
+                 dl2w, dl2b)
+        return (dx, None, None, None) + grads
+
+
+def _layer_params(layer):
+    at, out = layer.attention, layer.output
+    s = at.self
+    return (s.query.weight, s.query.bias, s.key.weight, s.key.bias, s.value.weight, s.value.bias,
+            at.output.dense.weight, at.output.dense.bias, at.output.LayerNorm.weight, at.output.LayerNorm.bias,
+            layer.intermediate.dense.weight, layer.intermediate.dense.bias, out.dense.weight, out.dense.bias,
+            out.LayerNorm.weight, out.LayerNorm.bias)
+
+
+def _layer_shadows(layer, heads, dh, dp):
+    cache = layer.__dict__.setdefault("_ctclip_shadow", ops.ShadowCache())
+    p = _layer_params(layer)
+
+    def build():
+        pad = lambda w: ops.pad_head_rows(w, heads, dh, dp)
+        padb = lambda b: ops.pad_head_rows(b[:, None], heads, dh, dp)[:, 0]
+        return {
+            "wqkv": torch.cat((pad(p[0]), pad(p[2]), pad(p[4])), 0).to(BF16).contiguous(),
+            "bqkv": torch.cat((padb(p[1]), padb(p[3]), padb(p[5]))).to(F32).contiguous(),
+            "wao": pad(p[6].t()).t().to(BF16).contiguous(),
+            "wi": p[10].to(BF16).contiguous(), "wo": p[12].to(BF16).contiguous(), "inter": p[10].shape[0],
+        }
+
+    return cache.get("bert", p, build)
+
+
+def bert_last_hidden_state(model, input_ids, token_type_ids=None, attention_mask=None, **unused):
+    """HIP forward of transformers.BertModel -> last_hidden_state [B, L, H] (f32, autograd-enabled)."""
+    cfg = model.config
+    if not input_ids.is_cuda:
+        raise RuntimeError("text encoder: MI355X HIP path only (no CPU fallback); move the token ids to cuda")
+    if getattr(cfg, "position_embedding_type", "absolute") not in (None, "absolute"):
+        raise NotImplementedError("only absolute position embeddings are implemented")
+    if cfg.hidden_act not in ("gelu",):
+        raise NotImplementedError(f"hidden_act={cfg.hidden_act!r}: only erf-GELU is implemented")
+    if model.training and (cfg.hidden_dropout_prob > 0 or cfg.attention_probs_dropout_prob > 0):
+        raise NotImplementedError("dropout inside the text encoder is not implemented on the HIP path: "
+                                  "construct the BertModel with hidden_dropout_prob=attention_probs_dropout_prob=0 "
+                                  "or call .eval() on it")
+    B, L = input_ids.shape
+    Hd, heads = cfg.hidden_size, cfg.num_attention_heads
+    if Hd % 8 or cfg.intermediate_size % 8:
+        raise ValueError("hidden/intermediate sizes must be multiples of 8 for the bf16 MFMA path")
+    dh = Hd // heads
+    dp = ops.head_pad(dh)
+    emb = model.embeddings
+    x = BertEmbedFn.apply(input_ids, token_type_ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
+                          emb.token_type_embeddings.weight, emb.LayerNorm.weight, emb.LayerNorm.bias,
+                          float(cfg.layer_norm_eps))
+    mask_add = None
+    if attention_mask is not None:
+        mask_add = ((1.0 - attention_mask.to(F32)) * torch.finfo(F32).min).contiguous()
+    lcfg = (B, L, heads, dh, dp, float(cfg.layer_norm_eps))
+    for layer in model.encoder.layer:
+        x = BertLayerFn.apply(x, mask_add, _layer_shadows(layer, heads, dh, dp), lcfg, *_layer_params(layer))
+    return x.reshape(B, L, Hd)

@@ -23,18 +23,19 @@ extern "C" {
 /* ---- GEMM (MFMA) -------------------------------------------------------------------------------
  * C[M,N] = alpha * opA(A) opB(B) (+bias[N]) (+resid[M,N]) ; act: 0 none, 1 erf-GELU.
  * a_kmajor=1: A is [M][K]; 0: A is [K][M].  b_kmajor=1: B is [N][K] (nn.Linear weight); 0: [K][N].
- * c_fp32: output f32 instead of bf16.  split_k>1: K is split over workgroups and C (f32) is
- * accumulated with atomics (caller pre-initialises C; bias/resid added once).
+ * c_fp32: output f32 instead of bf16.  accumulate=1: C (f32) += result with atomics (caller
+ * pre-initialises C; bias/resid added once); split_k>1 splits K over workgroups and needs accumulate.
  * Replaces every nn.Linear / einsum GEMM of the path: attention.py:47,50,118-119,124,142;
  * ctvit.py:50; ctclip.py:115-116,127; transformers BertSelfAttention/BertIntermediate/BertOutput
  * dense layers; and their autograd (dgrad: a_kmajor=1,b_kmajor=0; wgrad: 0,0). */
 int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const float* resid,
                      int M, int N, int K, long lda, long ldb, long ldc, long ldr,
-                     int a_kmajor, int b_kmajor, int c_fp32, int split_k, float alpha, int act, void* stream);
+                     int a_kmajor, int b_kmajor, int c_fp32, int split_k, int accumulate, float alpha, int act,
+                     void* stream);
 
-/* scores = A[M,K] B[N,K]^T without materialising them: per column n, arg-max over each 64-row slab of
- * M.  part_val/part_idx are [N][2*ceil(M/128)].  VQ nearest-code search, ctvit.py:118 (library
- * vector_quantize_pytorch, cosine-sim codebook). */
+/* scores = A[M,K] B[N,K]^T without materialising them: per column n, the top-2 (value, row) of each 64-row
+ * slab of M.  part_val/part_idx are [N][2*ceil(M/128)][2]; empty slots carry index 0x7fffffff.  VQ nearest-code
+ * search, ctvit.py:118 (library vector_quantize_pytorch, cosine-sim codebook). */
 int ctclip_gemm_argmax_partial(const void* A, const void* B, float* part_val, int* part_idx,
                                int M, int N, int K, long lda, long ldb, void* stream);
 
@@ -84,6 +85,70 @@ int ctclip_swap_middle_f32(const float* in, float* out, long B, int A, int C, in
 int ctclip_mean_mid_fwd(const float* x, void* y_bf16, float* y_f32, long B, int T, long F, void* stream);
 int ctclip_mean_mid_bwd(const float* dy, float* dx, long B, int T, long F, void* stream);
 int ctclip_add_f32(const float* a, const float* b, float* y, void* y_bf16, long n, void* stream);
+
+/* ---- PEG depthwise causal conv + residual, channels-last, memory order (attention.py:55-83,325) ----
+ * w27 is tap-major [27][d] (tap = (kt*3+kh)*3+kw), a transposed copy of dsconv.weight[d,1,3,3,3].
+ * residual=1 fuses the `+ x` of attention.py:325 (forward) / the `+ dy` of its backward. */
+int ctclip_peg_fwd(const float* x, const float* w27, const float* bias, float* y, void* y_bf16, long B, int T, int H,
+                   int W, int d, int residual, void* stream);
+int ctclip_peg_bwd_data(const float* dy, const float* w27, float* dx, void* dx_bf16, long B, int T, int H, int W, int d,
+                        int residual, void* stream);
+int ctclip_peg_bwd_weight(const float* dy, const float* x, float* dw27, float* dbias, long B, int T, int H, int W, int d,
+                          void* stream);
+
+/* ---- tubelet gather + LayerNorm(c*pt*p*p) -> bf16 GEMM operand [tokens, ldA] (ctvit.py:44-49) ----
+ * volume: [B,C,Dz,Hy,Wx] f32 or bf16; pad columns F..ldA-1 are written as zero. */
+int ctclip_patch_ln_fwd(const void* volume, int volume_is_bf16, const float* gamma, const float* beta, void* A_bf16,
+                        float* mean, float* rstd, int B, int C, int Dz, int Hy, int Wx, int pt, int p, long ldA,
+                        float eps, void* stream);
+int ctclip_patch_ln_bwd(const void* volume, int volume_is_bf16, const void* dA_bf16, long ldd, const float* mean,
+                        const float* rstd, float* dgamma, float* dbeta, int B, int C, int Dz, int Hy, int Wx, int pt,
+                        int p, void* stream);
+
+/* ---- row l2-normalisation (VQ input ctvit.py:118; latents ctclip.py:119-120) ---- */
+int ctclip_rownorm_fwd(const float* x, void* y_bf16, float* y_f32, float* inv_norm, long rows, int dim, float eps,
+                       void* stream);
+int ctclip_rownorm_bwd(const float* dy, const float* x, const float* inv_norm, float* dx, long rows, int dim, void* stream);
+
+/* ---- VQ: finalise arg-max + gather codebook rows; EMA codebook update (ctvit.py:117-118) ---- */
+/* n_cand candidates per token from ctclip_gemm_argmax_partial; those within `margin` of the best bf16 score are
+ * re-scored exactly in f32 (x*inv_norm . embed[c]); writes the arg-max and gathers its f32 codebook row. */
+int ctclip_vq_select(const float* part_val, const int* part_idx, int n_cand, const float* x, const float* inv_norm,
+                     const float* embed, long* idx_out, float* quant, long ntok, int dim, float margin, void* stream);
+int ctclip_vq_ema_accum(const float* x, const float* inv_norm, const long* idx, float* bins, float* embed_sum, long ntok,
+                        int dim, void* stream);
+int ctclip_vq_ema_update(float* embed, float* cluster, const float* bins, const float* embed_sum, int ncodes, int dim,
+                         float decay, void* stream);
+
+/* ---- f32 tail: generic f32 GEMM (same layout flags as ctclip_gemm_bf16; act 2 = leaky_relu(slope),
+ * 3 = multiply by leaky_relu'(aux)); alpha_dev: optional device scalar multiplied in (exp'd if alpha_exp)
+ * -- the `* self.temperature.exp()` of ctclip.py:127; position-bias MLP attention.py:272-277 ---- */
+int ctclip_gemm_f32(const float* A, const float* B, float* C, const float* bias, const float* aux, int M, int N, int K,
+                    long lda, long ldb, long ldc, long ldaux, int a_kmajor, int b_kmajor, float alpha,
+                    const float* alpha_dev, int alpha_exp, int act, float slope, int accumulate, void* stream);
+/* symmetric InfoNCE with targets=arange (CTClipTrainer.py:164-175): loss scalar + dloss/dsim; workspace 2*G floats */
+int ctclip_infonce(const float* sim, float* loss, float* dsim, int G, float* workspace, void* stream);
+/* bias[h][i][j] = table[relidx[i][j]][h]: expands the de-duplicated position-bias table (attention.py:277) */
+int ctclip_bias_expand(const float* table, const uint16_t* relidx, float* bias, int heads, int n, void* stream);
+int ctclip_scale_by_dev(const float* x, const float* s, float* y, long n, void* stream);
+/* out[c] += sum_r x[r][c] (bias gradients); x is f32 or bf16 with row stride ld */
+int ctclip_colsum_accum(const void* x, int x_is_bf16, long rows, int cols, long ld, float* out, void* stream);
+/* y = dy * (act > 0 ? 1 : slope): backward of leaky_relu given its OUTPUT (attention.py:18-19) */
+int ctclip_leaky_bwd(const float* dy, const float* act, float* y, long n, float slope, void* stream);
+int ctclip_dot_accum(const float* a, const float* b, float* out, long n, void* stream);
+
+/* ---- optimiser (CTClipTrainer.py:199-202, optimizer.py:42-54): out += sum(g^2); clip + Adam/AdamW over a flat
+ * arena, clip coefficient min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) computed on device; optional bf16 shadow ---- */
+int ctclip_sumsq_accum(const float* g, long n, float* out, void* stream);
+int ctclip_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int decoupled, float bias_corr1, float bias_corr2,
+                     const float* gnorm_sq, float max_norm, void* stream);
+
+/* ---- BERT embeddings (transformers BertEmbeddings): word[ids] + pos[0..L) + type[token_type] ---- */
+int ctclip_bert_embed_fwd(const long* ids, const long* token_type, const float* word, const float* pos, const float* type,
+                          float* out, long rows, int L, int hidden, void* stream);
+int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* dy, float* dword, float* dpos,
+                          float* dtype, long rows, int L, int hidden, void* stream);
 
 #ifdef __cplusplus
 }

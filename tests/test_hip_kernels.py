@@ -54,10 +54,10 @@ def test_gemm_layouts(hip, akm, bkm, M, N, K):
     Bm = B.float().t() if bkm else B.float()
     ref = Am @ Bm
     C = torch.empty(M, N, device=DEV, dtype=torch.float32)
-    hip.gemm_bf16(A, B, C, None, None, M, N, K, A.stride(0), B.stride(0), N, 0, akm, bkm, 1, 1, 1.0, 0)
+    hip.gemm_bf16(A, B, C, None, None, M, N, K, A.stride(0), B.stride(0), N, 0, akm, bkm, 1, 1, 0, 1.0, 0)
     check(f"gemm f32 ({akm},{bkm}) {M}x{N}x{K}", C, ref, 2e-3)
     C16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-    hip.gemm_bf16(A, B, C16, None, None, M, N, K, A.stride(0), B.stride(0), N, 0, akm, bkm, 0, 1, 1.0, 0)
+    hip.gemm_bf16(A, B, C16, None, None, M, N, K, A.stride(0), B.stride(0), N, 0, akm, bkm, 0, 1, 0, 1.0, 0)
     check(f"gemm bf16 ({akm},{bkm})", C16, ref, 1e-2)
 
 
@@ -67,11 +67,11 @@ def test_gemm_mfma_orientation_asymmetric(hip):
     A = bf(torch.eye(n, device=DEV))
     Bw = bf(torch.arange(n * n, device=DEV, dtype=torch.float32).reshape(n, n) % 251)   # exact in bf16
     C = torch.empty(n, n, device=DEV, dtype=torch.float32)
-    hip.gemm_bf16(A, Bw, C, None, None, n, n, n, n, n, n, 0, 1, 1, 1, 1, 1.0, 0)       # C = I @ Bw^T
+    hip.gemm_bf16(A, Bw, C, None, None, n, n, n, n, n, n, 0, 1, 1, 1, 1, 0, 1.0, 0)    # C = I @ Bw^T
     assert torch.equal(C, Bw.float().t())
-    hip.gemm_bf16(A, Bw, C, None, None, n, n, n, n, n, n, 0, 1, 0, 1, 1, 1.0, 0)       # C = I @ Bw
+    hip.gemm_bf16(A, Bw, C, None, None, n, n, n, n, n, n, 0, 1, 0, 1, 1, 0, 1.0, 0)    # C = I @ Bw
     assert torch.equal(C, Bw.float())
-    hip.gemm_bf16(Bw, A, C, None, None, n, n, n, n, n, n, 0, 0, 1, 1, 1, 1.0, 0)       # C = Bw^T @ I
+    hip.gemm_bf16(Bw, A, C, None, None, n, n, n, n, n, n, 0, 0, 1, 1, 1, 0, 1.0, 0)    # C = Bw^T @ I
     assert torch.equal(C, Bw.float().t())
 
 
@@ -81,36 +81,48 @@ def test_gemm_epilogues_and_splitk(hip):
     bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
     ref = A.float() @ B.float().t()
     C = torch.empty(M, N, device=DEV)
-    hip.gemm_bf16(A, B, C, bias, res, M, N, K, K, K, N, N, 1, 1, 1, 1, 0.5, 0)
+    hip.gemm_bf16(A, B, C, bias, res, M, N, K, K, K, N, N, 1, 1, 1, 1, 0, 0.5, 0)
     check("bias+resid+alpha", C, 0.5 * ref + bias + res, 2e-3)
-    hip.gemm_bf16(A, B, C, bias, None, M, N, K, K, K, N, 0, 1, 1, 1, 1, 1.0, 1)
+    hip.gemm_bf16(A, B, C, bias, None, M, N, K, K, K, N, 0, 1, 1, 1, 1, 0, 1.0, 1)
     check("gelu", C, torch.nn.functional.gelu(ref + bias), 2e-3)
     C.copy_(res)
-    hip.gemm_bf16(A, B, C, bias, None, M, N, K, K, K, N, 0, 1, 1, 1, 5, 1.0, 0)
+    hip.gemm_bf16(A, B, C, bias, None, M, N, K, K, K, N, 0, 1, 1, 1, 5, 1, 1.0, 0)
     check("split-k atomic accumulate", C, ref + bias + res, 2e-3)
     # strided output / operand views (ld > extent)
     big = torch.zeros(M, N + 24, device=DEV)
-    hip.gemm_bf16(A, B, big, None, None, M, N, K, K, K, N + 24, 0, 1, 1, 1, 1, 1.0, 0)
+    hip.gemm_bf16(A, B, big, None, None, M, N, K, K, K, N + 24, 0, 1, 1, 1, 1, 0, 1.0, 0)
     check("ldc > N", big[:, :N], ref, 2e-3)
     assert float(big[:, N:].abs().max()) == 0.0
 
 
-def test_gemm_argmax_partial(hip):
+def test_gemm_argmax_partial_and_exact_select(hip):
     C_, T, K = 320, 200, 64
-    E = bf(torch.nn.functional.normalize(rnd(C_, K, seed=7), dim=-1))
-    X = bf(torch.nn.functional.normalize(rnd(T, K, seed=8), dim=-1))
-    parts = 2 * ((C_ + 127) // 128)
-    pv = torch.full((T, parts), float("nan"), device=DEV)
-    pi = torch.full((T, parts), -1, device=DEV, dtype=torch.int32)
+    Ef = torch.nn.functional.normalize(rnd(C_, K, seed=7), dim=-1).contiguous()
+    Xraw = (rnd(T, K, seed=8) * 3).contiguous()
+    # plant exact near-ties that bf16 scoring cannot resolve: token t is 1e-4 closer to code c2 than to c1
+    for t, (c1, c2) in enumerate([(5, 70), (200, 201), (319, 3)]):
+        Xraw[t] = (Ef[c1] + Ef[c2]) * 2 + 2e-4 * (Ef[c2] - Ef[c1])
+    inv = 1.0 / Xraw.norm(dim=-1)
+    E, X = bf(Ef), bf(Xraw * inv[:, None])
+    ncand = 4 * ((C_ + 127) // 128)
+    pv = torch.full((T, ncand), float("nan"), device=DEV)
+    pi = torch.full((T, ncand), -1, device=DEV, dtype=torch.int32)
     hip.gemm_argmax_partial(E, X, pv, pi, C_, T, K, K, K)
-    scores = X.float() @ E.float().t()                       # [T, C]
-    best = pv.argmax(dim=1)
-    idx = pi.gather(1, best[:, None])[:, 0].long()
-    ref_idx = scores.argmax(dim=1)
-    got_val = scores.gather(1, idx[:, None])[:, 0]
-    ref_val = scores.max(dim=1).values
-    assert float((ref_val - got_val).max()) <= 1e-5, "selected code must attain the max score (ties aside)"
-    assert float((idx == ref_idx).float().mean()) > 0.99
+    s16 = X.float() @ E.float().t()                          # what the MFMA pass scores
+    valid = pi != 0x7fffffff
+    best = torch.where(valid, pv, torch.full_like(pv, -1e30)).max(dim=1)
+    got16 = s16.gather(1, pi.gather(1, best.indices[:, None]).long())[:, 0]
+    assert float((s16.max(dim=1).values - got16).abs().max()) <= 1e-5, "slab top-2 must contain the bf16 arg-max"
+    idx = torch.empty(T, dtype=torch.long, device=DEV)
+    quant = torch.empty(T, K, device=DEV)
+    hip.vq_select(pv, pi, ncand, Xraw, inv, Ef, idx, quant, T, K, 2.0 ** -7)
+    exact = (Xraw * inv[:, None]) @ Ef.t()
+    ref = exact.argmax(dim=1)
+    gap = exact.max(dim=1).values - exact.gather(1, idx[:, None])[:, 0]
+    assert float(gap.max()) <= 2e-7, "selected code must attain the exact f32 maximum"
+    assert float((idx == ref).float().mean()) >= 0.995
+    assert torch.equal(idx[:3].cpu(), torch.tensor([70, 201, 3]))
+    assert torch.equal(quant, Ef[idx])
 
 
 # ---------------------------------------------------------------------------------------------- norms
