@@ -41,6 +41,7 @@ struct AttnArgs {
   const uint16_t* relidx;    // [n, n] or null
   float* dbias_table;        // [H, R] or null
   int table_size;            // R
+  int grid_h, grid_w;        // >0: relidx[i][j] = (yi-yj+h-1)*(2w-1) + (xi-xj+w-1) computed on the fly (i = y*w + x)
   long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int nseq, n, n_pad, heads;
   float scale;
@@ -120,10 +121,11 @@ __device__ __forceinline__ void store_rows(bf16_t* __restrict__ rowptr, const f3
     }
 }
 
-// scores of one 32x32 tile in "row of accumulator = key, lane = query" orientation
-// v[reg] = acc*scale + bias[head][q][key] + mask[key]; keys >= n -> -inf
-__device__ __forceinline__ void score_keymajor(f32x16& s, const AttnArgs& a, int head, int seq, int qrow_c, int key_base,
-                                               int half) {
+// additive terms of one 32x32 score tile in "row of accumulator = key, lane = query" orientation:
+// add[reg] = bias[head][q][key] + mask[key]  (0 where absent).  Issued one tile AHEAD of its use so the L2
+// latency of the bias rows hides behind the previous tile's MFMA + softmax work.
+__device__ __forceinline__ void load_addend(float (&add)[16], const AttnArgs& a, int head, int seq, int qrow_c, int key_base,
+                                            int half) {
   const float* brow = a.bias ? a.bias + ((long)head * a.n + qrow_c) * a.n : nullptr;
   const float* mrow = a.mask ? a.mask + (long)seq * a.n : nullptr;
 #pragma unroll
@@ -139,13 +141,21 @@ __device__ __forceinline__ void score_keymajor(f32x16& s, const AttnArgs& a, int
         for (int i = 0; i < 4; ++i) if (k0 + i < a.n) b[i] = brow[k0 + i];
       }
     }
+    if (mrow) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int key = k0 + i;
-      float v = s[4 * g4 + i] * a.scale + b[i];
-      if (mrow && key < a.n) v += mrow[key];
-      s[4 * g4 + i] = (key < a.n) ? v : -INFINITY;
+      for (int i = 0; i < 4; ++i) if (k0 + i < a.n) b[i] += mrow[k0 + i];
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) add[4 * g4 + i] = b[i];
+  }
+}
+
+// v[reg] = acc*scale + add[reg]; keys >= n -> -inf
+__device__ __forceinline__ void apply_scores(f32x16& s, const float (&add)[16], const AttnArgs& a, int key_base, int half) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int key = key_base + acc_row(i, half);
+    s[i] = (key < a.n) ? s[i] * a.scale + add[i] : -INFINITY;
   }
 }
 
@@ -153,16 +163,14 @@ __device__ __forceinline__ void score_keymajor(f32x16& s, const AttnArgs& a, int
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 16, DT = D / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int head = blockIdx.y, seq = blockIdx.z;
   const int half = lane >> 5;
-  char* kimg = smem;
-  char* vimg = smem + (size_t)a.n_pad * D * 2;
+  char* vimg = smem;
   const long row_base = (long)seq * a.n;
-  load_image<D>(kimg, a.k + row_base * a.ldk + head * D, a.ldk, a.n, a.n_pad, tid, blockDim.x);
   load_image<D>(vimg, a.v + row_base * a.ldv + head * D, a.ldv, a.n, a.n_pad, tid, blockDim.x);
   __syncthreads();
 
@@ -180,12 +188,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) zero_acc(oacc[dt]);
 
+  // K is only read row-wise: its fragments come straight from L2 (every wave of the workgroup reads the same rows),
+  // one tile ahead, which leaves LDS to the V image and doubles the workgroups resident per CU.
+  const bf16_t* kbase = a.k + row_base * a.ldk + head * D;
+  auto load_k = [&](bf16x8 (&dst)[KS], int kt) {
+    const int key = kt + (lane & 31);
+    const bool ok = key < a.n;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) dst[ks] = gfrag(kbase + (long)(ok ? key : 0) * a.ldk, ks, lane, ok);
+  };
+  float add_cur[16], add_nxt[16];
+  bf16x8 kf_cur[KS], kf_nxt[KS];
+  load_addend(add_cur, a, head, seq, qrow_c, 0, half);
+  load_k(kf_cur, 0);
   for (int kt = 0; kt < a.n_pad; kt += 32) {
+    if (kt + 32 < a.n_pad) {
+      load_addend(add_nxt, a, head, seq, qrow_c, kt + 32, half);
+      load_k(kf_nxt, kt + 32);
+    }
     f32x16 s;
     zero_acc(s);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<D>(kimg, kt, ks, lane), qf[ks], s);
-    score_keymajor(s, a, head, seq, qrow_c, kt, half);
+    for (int ks = 0; ks < KS; ++ks) s = mfma32(kf_cur[ks], qf[ks], s);
+    apply_scores(s, add_cur, a, kt, half);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) add_cur[i] = add_nxt[i];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf_cur[ks] = kf_nxt[ks];
     float tmax = s[0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
@@ -222,20 +251,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // backward pass 1: dQ, delta = rowsum(dO * O), d(bias)
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_bwd_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 16, DT = D / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int head = blockIdx.y, seq = blockIdx.z;
   const int half = lane >> 5;
   char* kimg = smem;
-  char* vimg = smem + (size_t)a.n_pad * D * 2;
-  float* table = (float*)(smem + (size_t)a.n_pad * D * 4);
+  float* table = (float*)(smem + (size_t)a.n_pad * D * 2);
+  int* keyoff = (int*)(table + ((a.table_size + 3) & ~3));
   const long row_base = (long)seq * a.n;
   load_image<D>(kimg, a.k + row_base * a.ldk + head * D, a.ldk, a.n, a.n_pad, tid, blockDim.x);
-  load_image<D>(vimg, a.v + row_base * a.ldv + head * D, a.ldv, a.n, a.n_pad, tid, blockDim.x);
-  if (a.dbias_table)
+  if (a.dbias_table) {
     for (int i = tid; i < a.table_size; i += blockDim.x) table[i] = 0.f;
+    if (a.grid_w > 0)
+      for (int i = tid; i < a.n_pad; i += blockDim.x) keyoff[i] = (i / a.grid_w) * (2 * a.grid_w - 1) + (i % a.grid_w);
+  }
   __syncthreads();
 
   const int q0 = (blockIdx.x * nwaves + wave) * 32;
@@ -258,27 +289,60 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     dsum += __shfl_xor(dsum, 32, 64);
     if (valid && half == 0) a.delta[stat] = dsum;
     const float lse = a.lse[stat];
+    const int qoff = (a.grid_w > 0)
+                         ? (qrow_c / a.grid_w + a.grid_h - 1) * (2 * a.grid_w - 1) + (qrow_c % a.grid_w + a.grid_w - 1)
+                         : 0;
 
     f32x16 dqacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) zero_acc(dqacc[dt]);
 
+    // V is only read row-wise here: fragments straight from L2, one tile ahead (see attn_fwd_kernel)
+    const bf16_t* vbase = a.v + row_base * a.ldv + head * D;
+    auto load_v = [&](bf16x8 (&dst)[KS], int kt) {
+      const int key = kt + (lane & 31);
+      const bool ok = key < a.n;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) dst[ks] = gfrag(vbase + (long)(ok ? key : 0) * a.ldv, ks, lane, ok);
+    };
+    float add_cur[16], add_nxt[16];
+    bf16x8 vf_cur[KS], vf_nxt[KS];
+    load_addend(add_cur, a, head, seq, qrow_c, 0, half);
+    load_v(vf_cur, 0);
     for (int kt = 0; kt < a.n_pad; kt += 32) {
+      if (kt + 32 < a.n_pad) {
+        load_addend(add_nxt, a, head, seq, qrow_c, kt + 32, half);
+        load_v(vf_nxt, kt + 32);
+      }
       f32x16 s, dp;
       zero_acc(s);
       zero_acc(dp);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         s = mfma32(row_frag<D>(kimg, kt, ks, lane), qf[ks], s);
-        dp = mfma32(row_frag<D>(vimg, kt, ks, lane), dof[ks], dp);
+        dp = mfma32(vf_cur[ks], dof[ks], dp);
       }
-      score_keymajor(s, a, head, seq, qrow_c, kt, half);
+      apply_scores(s, add_cur, a, kt, half);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) add_cur[i] = add_nxt[i];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) vf_cur[ks] = vf_nxt[ks];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float p = valid ? __expf(s[i] - lse) : 0.f;  // -inf scores -> 0
         s[i] = p * (dp[i] - dsum);                          // dS^T[key][q]
       }
-      if (valid && (a.dbias_dense || a.dbias_table)) {
+      if (valid && a.dbias_table && a.grid_w > 0) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int k0 = kt + 8 * g4 + 4 * half;
+          const int4 ko = *(const int4*)(keyoff + k0);
+          const int kk[4] = {ko.x, ko.y, ko.z, ko.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (k0 + i < a.n) atomicAdd(&table[qoff - kk[i]], s[4 * g4 + i]);
+        }
+      } else if (valid && (a.dbias_dense || a.dbias_table)) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int key = kt + acc_row(i, half);
@@ -310,7 +374,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // backward pass 2: dK, dV (each wave owns 32 keys, sweeps all query tiles)
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(D == 32 ? 384 : 256) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 16, DT = D / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -350,7 +414,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     zero_acc(dkacc[dt]);
     zero_acc(dvacc[dt]);
   }
+  float bcur[16], bnxt[16];
+  auto load_bcol = [&](float (&dst)[16], int qt) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = qt + acc_row(i, half);
+      dst[i] = (bcol && q < a.n) ? bcol[(long)q * a.n] : 0.f;
+    }
+  };
+  load_bcol(bcur, 0);
   for (int qt = 0; qt < a.n_pad; qt += 32) {
+    if (qt + 32 < a.n_pad) load_bcol(bnxt, qt + 32);
     f32x16 s, dp;
     zero_acc(s);
     zero_acc(dp);
@@ -367,14 +441,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int q = qb + i;
-        float v = s[4 * g4 + i] * a.scale + mval;
-        if (bcol && q < a.n) v += bcol[(long)q * a.n];
+        const float v = s[4 * g4 + i] * a.scale + mval + bcur[4 * g4 + i];
         const float p = valid ? __expf(v - ls[i]) : 0.f;
         s[4 * g4 + i] = p;
         dp[4 * g4 + i] = p * (dp[4 * g4 + i] - de[i]);
       }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bcur[i] = bnxt[i];
     const bf16x8 p0 = acc_frag(s, 0), p1 = acc_frag(s, 1), d0 = acc_frag(dp, 0), d1 = acc_frag(dp, 1);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -394,7 +468,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 // materialise probabilities (only for callers that ask Attention.forward for them, attention.py:182)
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void attn_probs_kernel(AttnArgs a, float* __restrict__ probs) {
+__global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_probs_kernel(AttnArgs a, float* __restrict__ probs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -419,7 +493,9 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(AttnArgs a, float* __re
     zero_acc(s);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<D>(kimg, kt, ks, lane), qf[ks], s);
-    score_keymajor(s, a, head, seq, qrow_c, kt, half);
+    float add[16];
+    load_addend(add, a, head, seq, qrow_c, kt, half);
+    apply_scores(s, add, a, kt, half);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int key = kt + acc_row(i, half);
@@ -435,9 +511,15 @@ int check(const AttnArgs& a, int dhead) {
   return 0;
 }
 
-inline int waves_for(int n) {
-  const int tiles = (n + 31) / 32;
-  return tiles < 4 ? tiles : 4;  // 256-thread workgroups
+// waves (32-row tiles) per workgroup: all of them share the LDS images of one (sequence, head), so more waves per
+// workgroup = fewer image loads and more waves per SIMD to hide the bias / LDS latency.  d_head 32 kernels are
+// compiled for up to 9 waves (n = 576 -> 2 workgroups of 9), d_head 64 for 4.
+inline int waves_for(int n, int dhead, int cap32 = 9) {
+  const int tiles = (n + 31) / 32, cap = (dhead == 32) ? cap32 : 4;
+  if (tiles <= cap) return tiles;
+  for (int w = cap; w >= 4; --w)
+    if (tiles % w == 0) return w;
+  return cap < 8 ? cap : 8;
 }
 
 }  // namespace
@@ -452,9 +534,9 @@ int ctclip_attn_fwd(const void* q, const void* k, const void* v, void* o, float*
   a.bias = bias; a.mask = mask; a.nseq = nseq; a.n = n; a.n_pad = (n + 31) / 32 * 32; a.heads = heads;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
   if (int e = check(a, dhead)) return e;
-  const int nw = waves_for(n);
+  const int nw = waves_for(n, dhead);
   dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
-  const size_t lds = (size_t)a.n_pad * dhead * 4;
+  const size_t lds = (size_t)a.n_pad * dhead * 2;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   if (dhead == 32) {
     if (lds > 65536) hipFuncSetAttribute((const void*)attn_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -468,21 +550,27 @@ int ctclip_attn_fwd(const void* q, const void* k, const void* v, void* o, float*
 
 int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
                     float* delta, void* dq, void* dk, void* dv, const float* bias, const float* mask,
-                    float* dbias_dense, const uint16_t* relidx, float* dbias_table, int table_size, int nseq, int n,
-                    int heads, int dhead, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk,
-                    long lddv, float scale, void* stream) {
+                    float* dbias_dense, const uint16_t* relidx, float* dbias_table, int table_size, int grid_h, int grid_w,
+                    int nseq, int n, int heads, int dhead, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq,
+                    long lddk, long lddv, float scale, void* stream) {
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.oin = (const bf16_t*)o;
   a.dO = (const bf16_t*)dO; a.lse = (float*)lse; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk;
   a.dv = (bf16_t*)dv; a.bias = bias; a.mask = mask; a.dbias_dense = dbias_dense; a.relidx = relidx;
-  a.dbias_table = (relidx && !dbias_dense) ? dbias_table : nullptr; a.table_size = table_size;
+  const bool grid_ok = grid_h > 0 && grid_w > 0 && grid_h * grid_w == n && table_size == (2 * grid_h - 1) * (2 * grid_w - 1);
+  if ((grid_h > 0 || grid_w > 0) && !grid_ok) return (int)hipErrorInvalidValue;
+  a.dbias_table = ((relidx || grid_ok) && !dbias_dense) ? dbias_table : nullptr; a.table_size = table_size;
+  a.grid_h = grid_ok ? grid_h : 0; a.grid_w = grid_ok ? grid_w : 0;
   a.nseq = nseq; a.n = n; a.n_pad = (n + 31) / 32 * 32; a.heads = heads;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.scale = scale;
   if (int e = check(a, dhead)) return e;
-  const int nw = waves_for(n);
+  const int nw = waves_for(n, dhead);
   dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
-  const size_t lds1 = (size_t)a.n_pad * dhead * 4 + (a.dbias_table ? (size_t)table_size * 4 : 0);
+  const int nw2 = waves_for(n, dhead, 6);   // dK/dV pass keeps 2x the accumulators: 6 waves -> 256-VGPR budget
+  dim3 grid2((a.n_pad / 32 + nw2 - 1) / nw2, heads, nseq), block2(nw2 * 64);
+  const size_t lds1 = (size_t)a.n_pad * dhead * 2 +
+                      (a.dbias_table ? (size_t)((table_size + 3) & ~3) * 4 + (size_t)a.n_pad * 4 : 0);
   const size_t lds2 = (size_t)a.n_pad * dhead * 4 + (size_t)a.n_pad * 8;
   if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
@@ -490,12 +578,12 @@ int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, 
     if (lds1 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (lds2 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, lds1, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid, block, lds2, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid2, block2, lds2, st, a);
   } else {
     if (lds1 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (lds2 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, lds1, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, lds2, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid2, block2, lds2, st, a);
   }
   CTCLIP_CHECK_LAUNCH();
 }
@@ -507,7 +595,7 @@ int ctclip_attn_probs(const void* q, const void* k, const float* lse, const floa
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.lse = (float*)lse; a.bias = bias; a.mask = mask;
   a.nseq = nseq; a.n = n; a.n_pad = (n + 31) / 32 * 32; a.heads = heads; a.ldq = ldq; a.ldk = ldk; a.scale = scale;
   if (int e = check(a, dhead)) return e;
-  const int nw = waves_for(n);
+  const int nw = waves_for(n, dhead);
   dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
   const size_t lds = (size_t)a.n_pad * dhead * 2;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;

@@ -76,10 +76,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             float* __restrict__ dx, bf16_t* __restrict__ dx16,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int rows, int dim) {
+  extern __shared__ __attribute__((aligned(16))) float lnred[];   // [2][dim]
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
   const int nv = dim >> 2;
+  for (int i = threadIdx.x; i < 2 * dim; i += 256) lnred[i] = 0.f;
+  __syncthreads();
   float4 ag[LN_NV], ab[LN_NV];
 #pragma unroll
   for (int i = 0; i < LN_NV; ++i) {
@@ -133,13 +136,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int i = 0; i < LN_NV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
-      float* pg = dgamma + c * 4;
+      float* pg = lnred + c * 4;
       atomicAdd(pg + 0, ag[i].x); atomicAdd(pg + 1, ag[i].y); atomicAdd(pg + 2, ag[i].z); atomicAdd(pg + 3, ag[i].w);
-      if (dbeta) {
-        float* pb = dbeta + c * 4;
-        atomicAdd(pb + 0, ab[i].x); atomicAdd(pb + 1, ab[i].y); atomicAdd(pb + 2, ab[i].z); atomicAdd(pb + 3, ab[i].w);
-      }
+      float* pb = lnred + dim + c * 4;
+      atomicAdd(pb + 0, ab[i].x); atomicAdd(pb + 1, ab[i].y); atomicAdd(pb + 2, ab[i].z); atomicAdd(pb + 3, ab[i].w);
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < dim; i += 256) {
+    atomicAdd(dgamma + i, lnred[i]);
+    if (dbeta) atomicAdd(dbeta + i, lnred[dim + i]);
   }
 }
 
@@ -263,9 +269,10 @@ int ctclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
   if (rows <= 0) return 0;
   if ((dim & 3) || dim > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
   int blocks = (rows + 3) / 4;
-  if (blocks > 2048) blocks = 2048;
-#define LN_BWD(NV)                                                                                                 \
-  hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, \
+  if (blocks > 1024) blocks = 1024;
+  const size_t lnlds = (size_t)2 * dim * sizeof(float);
+#define LN_BWD(NV)                                                                                                      \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(blocks), dim3(256), lnlds, (hipStream_t)stream, dy, x, gamma, mean, \
                      rstd, dres, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim)
   const int nv = (dim / 4 + 63) / 64;
   if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(16);

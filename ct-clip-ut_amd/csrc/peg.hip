@@ -18,111 +18,113 @@ __device__ __forceinline__ void fma4(float4& a, const float4& w, const float4& x
   a.x += w.x * x.x; a.y += w.y * x.y; a.z += w.z * x.z; a.w += w.w * x.w;
 }
 
-// y = x + bias + conv(x)                 out[t] uses x[t + kt - 2], x[h + kh - 1], x[w + kw - 1]
-__global__ __launch_bounds__(256) void peg_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w27,
-                                                      const float* __restrict__ bias, float* __restrict__ y,
-                                                      bf16_t* __restrict__ y16, Grid5 g, int residual) {
-  const long total = g.B * g.T * g.H * g.W * g.d4;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int c = (int)(idx % g.d4);
-    long pos = idx / g.d4;
-    const int w_ = (int)(pos % g.W);
-    const int h_ = (int)((pos / g.W) % g.H);
-    const int t_ = (int)((pos / ((long)g.W * g.H)) % g.T);
-    const long b = pos / ((long)g.W * g.H * g.T);
-    float4 acc = residual ? ((const float4*)x)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 bv = ((const float4*)bias)[c];
-    acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      const int tt = t_ + kt - 2;
-      if (tt < 0) continue;
-#pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
-        const int hh = h_ + kh - 1;
-        if (hh < 0 || hh >= g.H) continue;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int ww = w_ + kw - 1;
-          if (ww < 0 || ww >= g.W) continue;
-          const long np = ((b * g.T + tt) * g.H + hh) * g.W + ww;
-          fma4(acc, ((const float4*)w27)[((kt * 3 + kh) * 3 + kw) * g.d4 + c], ((const float4*)x)[np * g.d4 + c]);
-        }
-      }
-    }
-    if (y) ((float4*)y)[idx] = acc;
-    if (y16) {
-      uint2 p;
-      p.x = pack_bf16x2(acc.x, acc.y);
-      p.y = pack_bf16x2(acc.z, acc.w);
-      ((uint2*)y16)[idx] = p;
-    }
-  }
-}
+constexpr int PEG_CW = 8;   // outputs per thread along w
 
-// dx = dy + conv^T(dy):  x[pos] fed output (t - kt + 2, h - kh + 1, w - kw + 1) through tap (kt,kh,kw)
-__global__ __launch_bounds__(256) void peg_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w27,
-                                                           float* __restrict__ dx, bf16_t* __restrict__ dx16, Grid5 g,
-                                                           int residual) {
-  const long total = g.B * g.T * g.H * g.W * g.d4;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+// One thread owns 4 channels of PEG_CW consecutive w positions of one (b,t,h) row.  For each of the 9 (kt,kh) tap rows it
+// loads the PEG_CW+2 inputs once and slides the 3 kw taps over them in registers: 11.25 loads per output instead of 27.
+//   FWD : y[t,h,w]  = [x] + bias + sum w27[kt,kh,kw] * x[t+kt-2, h+kh-1, w+kw-1]                     (attention.py:73-76)
+//   !FWD: dx[t,h,w] = [dy]      + sum w27[kt,kh,kw] * dy[t-kt+2, h-kh+1, w-kw+1]                     (its transpose)
+template <bool FWD>
+__global__ __launch_bounds__(256) void peg_conv_kernel(const float* __restrict__ x, const float* __restrict__ w27,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       bf16_t* __restrict__ y16, Grid5 g, int residual) {
+  const int wchunks = (g.W + PEG_CW - 1) / PEG_CW;
+  const long total = g.B * g.T * g.H * wchunks * g.d4;
+  // one pass, no grid stride: block ids are remapped so each XCD walks a CONTIGUOUS range of (b,t,h) rows -- the
+  // h+-1 / t-1 / t-2 neighbour rows are then re-read from that XCD's own L2 instead of from HBM / Infinity Cache.
+  {
+    const long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (idx >= total) return;
     const int c = (int)(idx % g.d4);
-    long pos = idx / g.d4;
-    const int w_ = (int)(pos % g.W);
-    const int h_ = (int)((pos / g.W) % g.H);
-    const int t_ = (int)((pos / ((long)g.W * g.H)) % g.T);
-    const long b = pos / ((long)g.W * g.H * g.T);
-    float4 acc = residual ? ((const float4*)dy)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    long r = idx / g.d4;
+    const int wc = (int)(r % wchunks); r /= wchunks;
+    const int h_ = (int)(r % g.H); r /= g.H;
+    const int t_ = (int)(r % g.T);
+    const long b = r / g.T;
+    const int w0 = wc * PEG_CW;
+    const float4* xv = (const float4*)x;
+    float4 acc[PEG_CW];
+    const long row_c = ((b * g.T + t_) * g.H + h_) * g.W;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FWD) bv = ((const float4*)bias)[c];
+#pragma unroll
+    for (int i = 0; i < PEG_CW; ++i) {
+      acc[i] = bv;
+      if (residual && w0 + i < g.W) {
+        const float4 v = xv[(row_c + w0 + i) * g.d4 + c];
+        acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+      }
+    }
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
-      const int tt = t_ - kt + 2;
-      if (tt >= g.T) continue;
+      const int tt = FWD ? t_ + kt - 2 : t_ - kt + 2;
+      if (tt < 0 || tt >= g.T) continue;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        const int hh = h_ - kh + 1;
+        const int hh = FWD ? h_ + kh - 1 : h_ - kh + 1;
         if (hh < 0 || hh >= g.H) continue;
+        const long row = ((b * g.T + tt) * g.H + hh) * g.W;
+        float4 xs[PEG_CW + 2];
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int ww = w_ - kw + 1;
-          if (ww < 0 || ww >= g.W) continue;
-          const long np = ((b * g.T + tt) * g.H + hh) * g.W + ww;
-          fma4(acc, ((const float4*)w27)[((kt * 3 + kh) * 3 + kw) * g.d4 + c], ((const float4*)dy)[np * g.d4 + c]);
+        for (int i = 0; i < PEG_CW + 2; ++i) {
+          const int ww = w0 + i - 1;
+          xs[i] = (ww >= 0 && ww < g.W) ? xv[(row + ww) * g.d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4* wp = (const float4*)w27 + ((kt * 3 + kh) * 3) * g.d4 + c;
+        const float4 k0 = wp[0], k1 = wp[g.d4], k2 = wp[2 * g.d4];
+#pragma unroll
+        for (int i = 0; i < PEG_CW; ++i) {
+          if (FWD) { fma4(acc[i], k0, xs[i]); fma4(acc[i], k1, xs[i + 1]); fma4(acc[i], k2, xs[i + 2]); }
+          else     { fma4(acc[i], k2, xs[i]); fma4(acc[i], k1, xs[i + 1]); fma4(acc[i], k0, xs[i + 2]); }
         }
       }
     }
-    if (dx) ((float4*)dx)[idx] = acc;
-    if (dx16) {
-      uint2 p;
-      p.x = pack_bf16x2(acc.x, acc.y);
-      p.y = pack_bf16x2(acc.z, acc.w);
-      ((uint2*)dx16)[idx] = p;
+#pragma unroll
+    for (int i = 0; i < PEG_CW; ++i) {
+      if (w0 + i >= g.W) continue;
+      const long o = (row_c + w0 + i) * g.d4 + c;
+      if (y) ((float4*)y)[o] = acc[i];
+      if (y16) {
+        uint2 p;
+        p.x = pack_bf16x2(acc[i].x, acc[i].y);
+        p.y = pack_bf16x2(acc[i].z, acc[i].w);
+        ((uint2*)y16)[o] = p;
+      }
     }
   }
 }
 
 // dw27[tap][c] += sum_pos dy[pos][c] * x[pos + off(tap)][c];  dbias[c] += sum_pos dy[pos][c]
-// Each thread owns 4 channels and a strided subset of a position chunk; 28 float4 accumulators live in
-// registers and are flushed with atomics once per workgroup chunk.
-constexpr int PEG_CHUNK = 256;
+// Same sliding window: a thread owns 4 channels, walks w-chunks of a range of (b,t,h) rows, keeps the 27+1 float4
+// accumulators in registers and flushes them with atomics once.
+constexpr int PEG_ROWS_PER_BLOCK = 16;
 __global__ __launch_bounds__(256) void peg_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              float* __restrict__ dw27, float* __restrict__ dbias, Grid5 g) {
-  const int lanes_per_pos = g.d4;                    // threads covering one position
-  const int npg = 256 / lanes_per_pos;               // positions processed concurrently
-  const int c = threadIdx.x % lanes_per_pos, pg = threadIdx.x / lanes_per_pos;
-  if (pg >= npg) return;
-  const long npos = g.B * g.T * g.H * g.W;
-  const long p0 = (long)blockIdx.x * PEG_CHUNK;
+  const int c = threadIdx.x % g.d4, grp = threadIdx.x / g.d4, ngrp = 256 / g.d4;
+  if (grp >= ngrp) return;
+  const int wchunks = (g.W + PEG_CW - 1) / PEG_CW;
+  const long nrows = g.B * g.T * g.H;
+  const long work0 = (long)xcd_remap(blockIdx.x, gridDim.x) * PEG_ROWS_PER_BLOCK * wchunks;
+  const long work1 = min(nrows * wchunks, work0 + (long)PEG_ROWS_PER_BLOCK * wchunks);
+  const float4* xv = (const float4*)x;
+  const float4* dv = (const float4*)dy;
   float4 acc[28];
 #pragma unroll
   for (int i = 0; i < 28; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
-  for (long pos = p0 + pg; pos < p0 + PEG_CHUNK && pos < npos; pos += npg) {
-    const int w_ = (int)(pos % g.W);
-    const int h_ = (int)((pos / g.W) % g.H);
-    const int t_ = (int)((pos / ((long)g.W * g.H)) % g.T);
-    const long b = pos / ((long)g.W * g.H * g.T);
-    const float4 d = ((const float4*)dy)[pos * g.d4 + c];
-    fma4(acc[27], d, one);
+  for (long wk = work0 + grp; wk < work1; wk += ngrp) {
+    const int wc = (int)(wk % wchunks);
+    long r = wk / wchunks;
+    const int h_ = (int)(r % g.H); r /= g.H;
+    const int t_ = (int)(r % g.T);
+    const long b = r / g.T;
+    const int w0 = wc * PEG_CW;
+    const long row_c = ((b * g.T + t_) * g.H + h_) * g.W;
+    float4 d[PEG_CW];
+#pragma unroll
+    for (int i = 0; i < PEG_CW; ++i) {
+      d[i] = (w0 + i < g.W) ? dv[(row_c + w0 + i) * g.d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc[27].x += d[i].x; acc[27].y += d[i].y; acc[27].z += d[i].z; acc[27].w += d[i].w;
+    }
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
       const int tt = t_ + kt - 2;
@@ -131,12 +133,18 @@ __global__ __launch_bounds__(256) void peg_bwd_weight_kernel(const float* __rest
       for (int kh = 0; kh < 3; ++kh) {
         const int hh = h_ + kh - 1;
         if (hh < 0 || hh >= g.H) continue;
+        const long row = ((b * g.T + tt) * g.H + hh) * g.W;
+        float4 xs[PEG_CW + 2];
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int ww = w_ + kw - 1;
-          if (ww < 0 || ww >= g.W) continue;
-          const long np = ((b * g.T + tt) * g.H + hh) * g.W + ww;
-          fma4(acc[(kt * 3 + kh) * 3 + kw], d, ((const float4*)x)[np * g.d4 + c]);
+        for (int i = 0; i < PEG_CW + 2; ++i) {
+          const int ww = w0 + i - 1;
+          xs[i] = (ww >= 0 && ww < g.W) ? xv[(row + ww) * g.d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < PEG_CW; ++i) {
+          fma4(acc[(kt * 3 + kh) * 3 + 0], d[i], xs[i]);
+          fma4(acc[(kt * 3 + kh) * 3 + 1], d[i], xs[i + 1]);
+          fma4(acc[(kt * 3 + kh) * 3 + 2], d[i], xs[i + 2]);
         }
       }
     }
@@ -150,7 +158,6 @@ __global__ __launch_bounds__(256) void peg_bwd_weight_kernel(const float* __rest
 
 inline unsigned grid_for(long work) {
   long b = (work + 255) / 256;
-  if (b > 4096) b = 4096;
   if (b < 1) b = 1;
   return (unsigned)b;
 }
@@ -164,8 +171,8 @@ int ctclip_peg_fwd(const float* x, const float* w27, const float* bias, float* y
   if (B * T * H * W <= 0) return 0;
   if (d & 3) return (int)hipErrorInvalidValue;
   Grid5 g{B, T, H, W, d / 4};
-  hipLaunchKernelGGL(peg_fwd_kernel, dim3(grid_for(B * T * H * W * g.d4)), dim3(256), 0, (hipStream_t)stream, x, w27,
-                     bias, y, (bf16_t*)y_bf16, g, residual);
+  hipLaunchKernelGGL(peg_conv_kernel<true>, dim3(grid_for(B * T * H * ((W + PEG_CW - 1) / PEG_CW) * g.d4)), dim3(256), 0,
+                     (hipStream_t)stream, x, w27, bias, y, (bf16_t*)y_bf16, g, residual);
   CTCLIP_CHECK_LAUNCH();
 }
 
@@ -174,8 +181,8 @@ int ctclip_peg_bwd_data(const float* dy, const float* w27, float* dx, void* dx_b
   if (B * T * H * W <= 0) return 0;
   if (d & 3) return (int)hipErrorInvalidValue;
   Grid5 g{B, T, H, W, d / 4};
-  hipLaunchKernelGGL(peg_bwd_data_kernel, dim3(grid_for(B * T * H * W * g.d4)), dim3(256), 0, (hipStream_t)stream, dy,
-                     w27, dx, (bf16_t*)dx_bf16, g, residual);
+  hipLaunchKernelGGL(peg_conv_kernel<false>, dim3(grid_for(B * T * H * ((W + PEG_CW - 1) / PEG_CW) * g.d4)), dim3(256), 0,
+                     (hipStream_t)stream, dy, w27, (const float*)nullptr, dx, (bf16_t*)dx_bf16, g, residual);
   CTCLIP_CHECK_LAUNCH();
 }
 
@@ -185,8 +192,9 @@ int ctclip_peg_bwd_weight(const float* dy, const float* x, float* dw27, float* d
   if (npos <= 0) return 0;
   if ((d & 3) || d / 4 > 256) return (int)hipErrorInvalidValue;
   Grid5 g{B, T, H, W, d / 4};
-  hipLaunchKernelGGL(peg_bwd_weight_kernel, dim3((unsigned)((npos + PEG_CHUNK - 1) / PEG_CHUNK)), dim3(256), 0,
-                     (hipStream_t)stream, dy, x, dw27, dbias, g);
+  const long nrows = B * T * H;
+  hipLaunchKernelGGL(peg_bwd_weight_kernel, dim3((unsigned)((nrows + PEG_ROWS_PER_BLOCK - 1) / PEG_ROWS_PER_BLOCK)),
+                     dim3(256), 0, (hipStream_t)stream, dy, x, dw27, dbias, g);
   CTCLIP_CHECK_LAUNCH();
 }
 

@@ -259,15 +259,16 @@ class AttentionFn(Function):
         dkv = torch.empty(M, 2 * inner, dtype=BF16, device=dev)
         delta = torch.empty(nseq, heads, n, dtype=F32, device=dev)
         dbias_dense = dtable = rel = None
-        tsize = 0
+        tsize = gh = gw = 0
         if kind == "dense" and ctx.needs_input_grad[7]:
             dbias_dense = torch.zeros(heads, n, n, dtype=F32, device=dev)
         elif kind == "table":
             tsize = aux["rows"]
             dtable = torch.zeros(heads, tsize, dtype=F32, device=dev)
-            rel = aux["relidx"]
+            gh, gw = aux.get("grid", (0, 0))
+            rel = None if gw else aux["relidx"]
         hip.attn_bwd(qh, kh, kv[:, inner:], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, None,
-                     dbias_dense, rel, dtable, tsize, nseq, n, heads, dp,
+                     dbias_dense, rel, dtable, tsize, gh, gw, nseq, n, heads, dp,
                      inner, inner, 2 * inner, inner, inner, inner, inner, 2 * inner, 1.0)
         dq = torch.empty(M, inner, dtype=BF16, device=dev)
         dqs = torch.zeros(dp, dtype=F32, device=dev)

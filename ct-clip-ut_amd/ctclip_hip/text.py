@@ -120,7 +120,7 @@ class BertLayerFn(Function):
         dqkv = torch.empty(M, 3 * inner, dtype=BF16, device=dev)
         delta = torch.empty(B, heads, L, dtype=F32, device=dev)
         hip.attn_bwd(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, do, lse, delta, dqkv, dqkv[:, inner:],
-                     dqkv[:, 2 * inner:], None, mask_add, None, None, None, 0, B, L, heads, dp,
+                     dqkv[:, 2 * inner:], None, mask_add, None, None, None, 0, 0, 0, B, L, heads, dp,
                      3 * inner, 3 * inner, 3 * inner, inner, inner, 3 * inner, 3 * inner, 3 * inner,
                      1.0 / math.sqrt(dh))
         dbqkv = ops.colsum(dqkv)

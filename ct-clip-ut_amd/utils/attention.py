@@ -124,8 +124,8 @@ class PositionBias:
     (what the reference materialises, attention.py:277); attention backward reduces d(bias) on chip into
     d(table)."""
 
-    def __init__(self, table, relidx, dense):
-        self.table, self.relidx, self.dense = table, relidx, dense
+    def __init__(self, table, relidx, dense, grid=None):
+        self.table, self.relidx, self.dense, self.grid = table, relidx, dense, grid
         self.rows = table.shape[0]
 
 
@@ -187,7 +187,8 @@ class Attention(nn.Module):
             bias_t, aux = None, {"kind": None}
         elif isinstance(attn_bias, PositionBias):
             bias_t = attn_bias.table
-            aux = {"kind": "table", "dense": attn_bias.dense, "relidx": attn_bias.relidx, "rows": attn_bias.rows}
+            aux = {"kind": "table", "dense": attn_bias.dense, "relidx": attn_bias.relidx, "rows": attn_bias.rows,
+                   "grid": attn_bias.grid or (0, 0)}
         else:
             bias_t, aux = attn_bias, {"kind": "dense"}
         y, probs = ops.AttentionFn.apply(x.to(F32), self.norm.gamma, self.to_q.weight, self.to_kv.weight, self.q_scale,
@@ -243,7 +244,7 @@ class ContinuousPositionBias(nn.Module):
         n = relidx.shape[0]
         dense = torch.empty(self.heads, n, n, dtype=F32, device=device)
         hip.bias_expand(table.detach(), relidx, dense, self.heads, n)
-        return PositionBias(table, relidx, dense)
+        return PositionBias(table, relidx, dense, grid=tuple(int(d) for d in dimensions))
 
     def forward(self, *dimensions, device=torch.device("cpu")):
         """Reference signature: returns the dense [heads, n, n] bias.  (The reference ignores `device` and

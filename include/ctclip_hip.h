@@ -60,13 +60,15 @@ int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, co
 int ctclip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
                     const float* mask, int nseq, int n, int heads, int dhead, long ldq, long ldk, long ldv, long ldo,
                     float scale, void* stream);
-/* d(bias): dense [heads,n,n] atomics if dbias_dense != NULL, else a [heads][table_size] table indexed by
- * relidx[n*n] (uint16) if relidx != NULL, else skipped.  delta: scratch [nseq,heads,n]. */
+/* d(bias): dense [heads,n,n] atomics if dbias_dense != NULL; else reduced on chip into a [heads][table_size] table
+ * indexed by relidx[n*n] (uint16) if relidx != NULL, or -- when grid_h*grid_w == n -- by the 2-D relative position
+ * (yi-yj+h-1)*(2w-1) + (xi-xj+w-1) computed on the fly (table_size = (2h-1)(2w-1), the CT-ViT position bias,
+ * attention.py:262-268); else skipped.  delta: scratch [nseq,heads,n]. */
 int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
                     float* delta, void* dq, void* dk, void* dv, const float* bias, const float* mask,
-                    float* dbias_dense, const uint16_t* relidx, float* dbias_table, int table_size, int nseq, int n,
-                    int heads, int dhead, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk,
-                    long lddv, float scale, void* stream);
+                    float* dbias_dense, const uint16_t* relidx, float* dbias_table, int table_size, int grid_h, int grid_w,
+                    int nseq, int n, int heads, int dhead, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq,
+                    long lddk, long lddv, float scale, void* stream);
 /* probabilities [nseq,heads,n,n] f32, for callers that want Attention.forward's second output */
 int ctclip_attn_probs(const void* q, const void* k, const float* lse, const float* bias, const float* mask,
                       float* probs, int nseq, int n, int heads, int dhead, long ldq, long ldk, float scale,

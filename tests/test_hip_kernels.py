@@ -223,7 +223,7 @@ def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask):
     dq, dk, dv = (torch.empty(nseq * n, ld, device=DEV, dtype=torch.bfloat16) for _ in range(3))
     delta = torch.empty(nseq, H, n, device=DEV)
     dbias = torch.zeros(H, n, n, device=DEV) if use_bias else None
-    hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, mask, dbias, None, None, 0, nseq, n, H, D,
+    hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, mask, dbias, None, None, 0, 0, 0, nseq, n, H, D,
                  ld, ld, ld, ld, ld, ld, ld, ld, scale)
     un = lambda t: t.float().reshape(nseq, n, H, D).permute(0, 2, 1, 3)
     check("attn dq", un(dq), qr.grad, 3e-2)
@@ -235,10 +235,21 @@ def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask):
         R = 37
         relidx = torch.randint(0, R, (n, n), generator=torch.Generator().manual_seed(3)).to(DEV)
         dt = torch.zeros(H, R, device=DEV)
-        hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, mask, None, relidx.to(torch.uint16), dt, R,
+        hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, mask, None, relidx.to(torch.uint16), dt, R, 0, 0,
                      nseq, n, H, D, ld, ld, ld, ld, ld, ld, ld, ld, scale)
         ref_t = torch.zeros(H, R, device=DEV).index_add_(1, relidx.reshape(-1), br.grad.reshape(H, -1))
         check("attn dbias table", dt, ref_t, 3e-2)
+        # 2-D relative-position mode (index computed on chip): n = gh*gw
+        gh = next(d for d in (24, 8, 5, 4, 3, 2, 1) if n % d == 0)
+        gw = n // gh
+        ii = torch.arange(n, device=DEV)
+        rel2 = ((ii[:, None] // gw - ii[None] // gw + gh - 1) * (2 * gw - 1) + (ii[:, None] % gw - ii[None] % gw + gw - 1))
+        R2 = (2 * gh - 1) * (2 * gw - 1)
+        dt2 = torch.zeros(H, R2, device=DEV)
+        hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, mask, None, None, dt2, R2, gh, gw,
+                     nseq, n, H, D, ld, ld, ld, ld, ld, ld, ld, ld, scale)
+        ref2 = torch.zeros(H, R2, device=DEV).index_add_(1, rel2.reshape(-1), br.grad.reshape(H, -1))
+        check("attn dbias 2-D grid table", dt2, ref2, 3e-2)
 
 
 # ---------------------------------------------------------------------------------------------- elementwise
