@@ -18,6 +18,7 @@
 // Block ids are remapped so each XCD's L2 sees a contiguous run of tiles (N fastest: blocks that
 // share an A row-panel run on one XCD).  split_k > 1 accumulates with f32 atomics.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -295,6 +296,105 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// VQ nearest-code search: one workgroup owns 128 tokens (the N side) and sweeps ALL code tiles (the M side), keeping a
+// running top-4 (value, code) per lane for each of its two token columns.  The [codes x tokens] score matrix never
+// exists; the cross-lane work and the stores happen once per token tile.  Each token ends with 4 lanes-groups x 4 = 16
+// candidates (disjoint quarters of the codebook), which ctclip_vq_select re-ranks exactly in f32.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int VQ_TOP = 4;
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_vq_topk_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int col0 = xcd_remap(blockIdx.x, gridDim.x) * BN;      // token tile
+  const int nk = (g.K + BKT - 1) / BKT;
+  const int steps = g.tiles_m * nk;                              // flattened (code tile, k tile) sequence
+  const int half = lane >> 5, lc = lane & 31;
+
+  float bv[2][VQ_TOP];
+  int bi[2][VQ_TOP];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int t = 0; t < VQ_TOP; ++t) { bv[j][t] = -INFINITY; bi[j][t] = 0x7fffffff; }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[4], rb[4];
+  load_tile_regs<true>(g.A, g.lda, 0, 0, g.M, g.K, ra, tid);
+  load_tile_regs<true>(g.B, g.ldb, col0, 0, g.N, g.K, rb, tid);
+  store_tile_lds<true>(smem, ra, tid);
+  store_tile_lds<true>(smem + TILE_BYTES, rb, tid);
+  __syncthreads();
+  for (int st = 0; st < steps; ++st) {
+    const int cur = st & 1;
+    const char* ta = smem + cur * 2 * TILE_BYTES;
+    const char* tb = ta + TILE_BYTES;
+    const bool more = (st + 1) < steps;
+    if (more) {
+      const int nt = (st + 1) / nk, nkt = (st + 1) % nk;
+      load_tile_regs<true>(g.A, g.lda, nt * BM, nkt * BKT, g.M, g.K, ra, tid);
+      load_tile_regs<true>(g.B, g.ldb, col0, nkt * BKT, g.N, g.K, rb, tid);
+    }
+#pragma unroll
+    for (int s = 0; s < BKT / 16; ++s) {
+      bf16x8 fa[2], fb[2];
+      fa[0] = read_frag<true>(ta, wm * 64, s, lane);
+      fa[1] = read_frag<true>(ta, wm * 64 + 32, s, lane);
+      fb[0] = read_frag<true>(tb, wn * 64, s, lane);
+      fb[1] = read_frag<true>(tb, wn * 64 + 32, s, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+    }
+    if ((st % nk) == nk - 1) {                                   // a code tile is complete: fold it into the running top-4
+      const int row_t = (st / nk) * BM + wm * 64;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            const int row = row_t + i * 32 + acc_row(r, half);
+            if (row < g.M && (v > bv[j][VQ_TOP - 1] || (v == bv[j][VQ_TOP - 1] && row < bi[j][VQ_TOP - 1]))) {
+              float cv = v; int ci = row;                        // insertion into the sorted 4-list (rarely taken)
+#pragma unroll
+              for (int t = 0; t < VQ_TOP; ++t) {
+                const bool better = cv > bv[j][t] || (cv == bv[j][t] && ci < bi[j][t]);
+                const float tv = bv[j][t]; const int ti = bi[j][t];
+                if (better) { bv[j][t] = cv; bi[j][t] = ci; cv = tv; ci = ti; }
+              }
+            }
+            acc[i][j][r] = 0.f;
+          }
+    }
+    if (more) {
+      char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      store_tile_lds<true>(na, ra, tid);
+      store_tile_lds<true>(na + TILE_BYTES, rb, tid);
+    }
+    __syncthreads();
+  }
+  // candidates: [token][ (wm*2 + half) * VQ_TOP + t ]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + wn * 64 + j * 32 + lc;
+    if (col >= g.N) continue;
+    const long p = (long)col * g.n_parts + (wm * 2 + half) * VQ_TOP;
+#pragma unroll
+    for (int t = 0; t < VQ_TOP; ++t) { g.part_val[p + t] = bv[j][t]; g.part_idx[p + t] = bi[j][t]; }
+  }
+}
+
 template <int EPI>
 int launch(const GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) {
   const int nblk = g.tiles_m * g.tiles_n * g.split_k;
@@ -307,11 +407,20 @@ int launch(const GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-bool bad_layout(const void* p, long ld, int contiguous_extent) {
-  return (((uintptr_t)p) & 15) != 0 || (ld & 7) != 0 || (contiguous_extent & 7) != 0;
+// 16-byte vector loads: base and row stride must be 8-element aligned.  A k-major operand needs K % 8 == 0 (the K tail is
+// zero-filled per vector); an m/n-major operand may have a ragged extent as long as the row stride covers the last
+// 8-element chunk (ld >= round_up(extent, 8)): the extra rows/columns it produces are masked in the epilogue.
+bool bad_layout(const void* p, long ld, int contiguous_extent, bool kmajor) {
+  if ((((uintptr_t)p) & 15) != 0 || (ld & 7) != 0) return true;
+  if (kmajor) return (contiguous_extent & 7) != 0;
+  return ld < ((contiguous_extent + 7) & ~7);
 }
 
 }  // namespace
+
+int ctclip_gemm2_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
+                        long lda, long ldb, long ldc, long ldr, int a_kmajor, int b_kmajor, int c_fp32, int split_k,
+                        int accumulate, float alpha, int act, hipStream_t st);
 
 extern "C" {
 
@@ -321,9 +430,24 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
                      int a_kmajor, int b_kmajor, int c_fp32, int split_k, int accumulate, float alpha, int act,
                      void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (bad_layout(A, lda, a_kmajor ? K : M) || bad_layout(B, ldb, b_kmajor ? K : N)) return (int)hipErrorInvalidValue;
+  if (bad_layout(A, lda, a_kmajor ? K : M, a_kmajor) || bad_layout(B, ldb, b_kmajor ? K : N, b_kmajor)) return (int)hipErrorInvalidValue;
   if (split_k > 1 && !accumulate) return (int)hipErrorInvalidValue;
   if (accumulate && (!c_fp32 || (act & 0xff) != 0)) return (int)hipErrorInvalidValue;
+  {
+    // Long-K k-major problems go to the pipelined 256x128 LDS-DMA kernel (gemm2.hip: 874-919 vs 748 TFLOP/s at
+    // 4096^3 / 8192^3).  The short-K (256..1408) and split-K shapes of the CT-CLIP step measured equal or faster on the
+    // register-staged 128x128 kernel below (two workgroups per CU overlap one tile's epilogue with another's main loop;
+    // tools/bench_gemm.py, profiles/r01_gemm_v1_v2.txt), so they stay here.  CTCLIP_GEMM_V2_ALL=1 widens the gate.
+    static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
+    if (!force_v1 && v2_all && (K % 64) == 0 && blocks2 >= 192)
+      return ctclip_gemm2_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, a_kmajor, b_kmajor, c_fp32, split_k,
+                                 accumulate, alpha, act, (hipStream_t)stream);
+    static const bool force_v1 = getenv("CTCLIP_GEMM_V1") != nullptr;
+    const long blocks2 = (long)((M + 255) / 256) * ((N + 127) / 128) * (split_k > 1 ? split_k : 1);
+    if (!force_v1 && (K % 64) == 0 && blocks2 >= 192 && a_kmajor && b_kmajor && K >= 2048 && split_k <= 1)
+      return ctclip_gemm2_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, a_kmajor, b_kmajor, c_fp32, split_k,
+                                 accumulate, alpha, act, (hipStream_t)stream);
+  }
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
@@ -337,12 +461,26 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
   return launch<0>(g, a_kmajor, b_kmajor, (hipStream_t)stream);
 }
 
-// scores[m][n] = sum_k A[m][k] B[n][k]; for every column n writes the top-2 over the rows of each
-// 64-row slab: part_val/part_idx are [N][n_parts][2], n_parts = 2*ceil(M/128) (index 0x7fffffff = empty).
+// scores[m][n] = sum_k A[m][k] B[n][k], never materialised; for every column n writes 16 candidates: the top-4 of each
+// of 4 disjoint row subsets.  part_val/part_idx are [N][16] (index 0x7fffffff = empty slot).
+int ctclip_vq_topk(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda, long ldb,
+                   void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true)) return (int)hipErrorInvalidValue;
+  GemmArgs g{};
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  g.part_val = part_val; g.part_idx = part_idx; g.n_parts = 4 * VQ_TOP;
+  hipLaunchKernelGGL(gemm_vq_topk_kernel, dim3(g.tiles_n), dim3(NTHREADS), 4 * TILE_BYTES, (hipStream_t)stream, g);
+  return (int)hipGetLastError();
+}
+
+// (older per-tile variant, kept for the kernel tests) top-2 over the rows of each 64-row slab:
+// part_val/part_idx are [N][n_parts][2], n_parts = 2*ceil(M/128) (index 0x7fffffff = empty).
 int ctclip_gemm_argmax_partial(const void* A, const void* B, float* part_val, int* part_idx,
                                int M, int N, int K, long lda, long ldb, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (bad_layout(A, lda, K) || bad_layout(B, ldb, K)) return (int)hipErrorInvalidValue;
+  if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true)) return (int)hipErrorInvalidValue;
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;

@@ -169,19 +169,25 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   }
 }
 
+// out[c] += sum_r x[r][c]: a workgroup covers 64 columns x rows_per_block rows, 4 row-lanes per column, LDS reduce,
+// one atomic per column per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long rows, int cols, long ld,
                                                      float* __restrict__ out, int rows_per_block) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   const long r0 = (long)blockIdx.y * rows_per_block;
   const long r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
   float s = 0.f;
-  for (long r = r0; r < r1; ++r) {
-    if (sizeof(T) == 2) s += bf16_to_f32(((const bf16_t*)x)[r * ld + c]);
-    else s += ((const float*)x)[r * ld + c];
-  }
-  atomicAdd(out + c, s);
+  if (c < cols)
+    for (long r = r0 + rl; r < r1; r += 4) {
+      if (sizeof(T) == 2) s += bf16_to_f32(((const bf16_t*)x)[r * ld + c]);
+      else s += ((const float*)x)[r * ld + c];
+    }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) atomicAdd(out + c, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
 }
 
 __global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ act,
@@ -232,8 +238,8 @@ int ctclip_scale_by_dev(const float* x, const float* s, float* y, long n, void* 
 
 int ctclip_colsum_accum(const void* x, int x_is_bf16, long rows, int cols, long ld, float* out, void* stream) {
   if (rows <= 0 || cols <= 0) return 0;
-  const int rpb = 256;
-  dim3 grid((cols + 255) / 256, (unsigned)((rows + rpb - 1) / rpb));
+  const int rpb = 128;
+  dim3 grid((cols + 63) / 64, (unsigned)((rows + rpb - 1) / rpb));
   if (x_is_bf16)
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, cols, ld, out, rpb);
   else

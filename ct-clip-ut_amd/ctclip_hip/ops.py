@@ -136,6 +136,20 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def grad_slot(p):
+    """-> (buffer, direct).  Every gradient kernel ACCUMULATES (f32 atomics), so when the parameter already owns a
+    contiguous f32 .grad (the flat arena of ctclip_hip.optim.HipAdam pre-binds one) the kernels add straight into
+    it and the Function returns None for that input: no zero-fill, no extra `grad += new` pass per tensor."""
+    g = p.grad
+    if g is not None and g.dtype == F32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device:
+        return g, True
+    return torch.zeros(p.shape, dtype=F32, device=p.device), False
+
+
+def _ret(buf, direct):
+    return None if direct else buf
+
+
 # ---------------------------------------------------------------------------------------------------
 # LayerNorm as a module-level op (Transformer.norm_out, patch-embed tail)
 # ---------------------------------------------------------------------------------------------------
@@ -145,19 +159,20 @@ class LayerNormFn(Function):
         shape = x.shape
         x2 = _c(x).reshape(-1, shape[-1])
         _, y, mean, rstd = layernorm(x2, gamma, beta, eps, want16=False, want32=True)
-        ctx.save_for_backward(x2, gamma, mean, rstd)
-        ctx.has_beta = beta is not None
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.params = (gamma, beta)
         return y.reshape(shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, gamma, mean, rstd = ctx.saved_tensors
+        x2, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
         dy2 = _c(dy).reshape(x2.shape)
         dx = torch.empty_like(x2)
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma) if ctx.has_beta else None
-        hip.layernorm_bwd(dy2, x2, gamma, mean, rstd, None, dx, None, dg, db, x2.shape[0], x2.shape[1])
-        return dx.reshape(dy.shape), dg, db, None
+        dg, dg_d = grad_slot(gamma)
+        db, db_d = grad_slot(beta) if beta is not None else (None, True)
+        hip.layernorm_bwd(dy2, x2, gamma.detach(), mean, rstd, None, dx, None, dg, db, x2.shape[0], x2.shape[1])
+        return dx.reshape(dy.shape), _ret(dg, dg_d), _ret(db, db_d), None
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -236,6 +251,7 @@ class AttentionFn(Function):
         ctx.save_for_backward(x2, gamma, mean, rstd, n1, xb, q, kv, qh, kh, qinv, kinv, o, lse,
                               bias_dense if bias_dense is not None else x2.new_empty(0))
         ctx.sh, ctx.cfg, ctx.aux, ctx.shape = sh, cfg, aux, (nseq, n, dim)
+        ctx.params = (gamma, wq, wkv, q_scale, k_scale, wout)
         ctx.mark_non_differentiable(probs)
         return y.reshape(nseq, n, dim), probs
 
@@ -253,7 +269,6 @@ class AttentionFn(Function):
         dy2 = _c(dy).reshape(M, dim)
         dyb = cast16(dy2)
         do = dgrad(dyb, sh["wout"], M, dim, inner, out_dtype=BF16)
-        dwout = wgrad(dyb, o, dim, inner, M)
         dqh = torch.empty(M, inner, dtype=BF16, device=dev)
         dkh = torch.empty(M, inner, dtype=BF16, device=dev)
         dkv = torch.empty(M, 2 * inner, dtype=BF16, device=dev)
@@ -270,7 +285,32 @@ class AttentionFn(Function):
         hip.attn_bwd(qh, kh, kv[:, inner:], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, None,
                      dbias_dense, rel, dtable, tsize, gh, gw, nseq, n, heads, dp,
                      inner, inner, 2 * inner, inner, inner, inner, inner, 2 * inner, 1.0)
+        p_gamma, p_wq, p_wkv, p_qs, p_ks, p_wout = ctx.params
         dq = torch.empty(M, inner, dtype=BF16, device=dev)
+        dbias = None
+        if kind == "dense":
+            dbias = dbias_dense
+        elif kind == "table":
+            dbias = dtable.t().contiguous()          # [R, heads] like the MLP output
+        dx = torch.empty(M, dim, dtype=F32, device=dev)
+        if dp == dh:                                   # production layout: gradients land in param-shaped buffers
+            gqs, d1 = grad_slot(p_qs)
+            gks, d2 = grad_slot(p_ks)
+            gwq, d3 = grad_slot(p_wq)
+            gwkv, d4 = grad_slot(p_wkv)
+            gwo, d5 = grad_slot(p_wout)
+            gg, d6 = grad_slot(p_gamma)
+            wgrad(dyb, o, dim, inner, M, out=gwo)
+            hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, inner, inner, float(scale))
+            hip.headnorm_bwd(dkh, kv, kinv, sh["k_scale"], dkv, gks, M, heads, dp, inner, 2 * inner, 2 * inner, 1.0)
+            dn1 = dgrad(dq, sh["wq"], M, inner, dim)
+            wgrad(dq, n1, inner, dim, M, out=gwq)
+            dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None)
+            wgrad(dkv, xb, 2 * inner, dim, M, out=gwkv)
+            hip.layernorm_bwd(dn1, x2, gamma, mean, rstd, dxkv, dx, None, gg, None, M, dim)
+            return (dx.reshape(nseq, n, dim), _ret(gg, d6), _ret(gwq, d3), _ret(gwkv, d4), _ret(gqs, d1), _ret(gks, d2),
+                    _ret(gwo, d5), dbias, None, None, None)
+        dwout = wgrad(dyb, o, dim, inner, M)
         dqs = torch.zeros(dp, dtype=F32, device=dev)
         dks = torch.zeros(dp, dtype=F32, device=dev)
         hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, dqs, M, heads, dp, inner, inner, inner, float(scale))
@@ -279,18 +319,12 @@ class AttentionFn(Function):
         dwq = wgrad(dq, n1, inner, dim, M)
         dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None)
         dwkv = wgrad(dkv, xb, 2 * inner, dim, M)
-        dx = torch.empty(M, dim, dtype=F32, device=dev)
         dgamma = torch.zeros_like(gamma)
         hip.layernorm_bwd(dn1, x2, gamma, mean, rstd, dxkv, dx, None, dgamma, None, M, dim)
         dwq = unpad_head_rows(dwq, heads, dh, dp)
         dwk = unpad_head_rows(dwkv[:inner], heads, dh, dp)
         dwv = unpad_head_rows(dwkv[inner:], heads, dh, dp)
         dwout = unpad_head_rows(dwout.t(), heads, dh, dp).t()
-        dbias = None
-        if kind == "dense":
-            dbias = dbias_dense
-        elif kind == "table":
-            dbias = dtable.t().contiguous()          # [R, heads] like the MLP output
         return (dx.reshape(nseq, n, dim), dgamma, dwq, torch.cat((dwk, dwv), 0), dqs[:dh], dks[:dh], dwout, dbias,
                 None, None, None)
 
@@ -313,6 +347,7 @@ class FeedForwardFn(Function):
         y = gemm(g, sh["w2"], M, dim, Ip, out_dtype=F32, resid=x2 if residual else None)
         ctx.save_for_backward(x2, ln_w, mean, rstd, n2, h, g)
         ctx.sh, ctx.residual = sh, residual
+        ctx.params = (ln_w, ln_b, w1, w2)
         return y.reshape(shape)
 
     @staticmethod
@@ -323,19 +358,21 @@ class FeedForwardFn(Function):
         I, Ip = sh["inner"], sh["inner_p"]
         dy2 = _c(dy).reshape(M, dim)
         dyb = cast16(dy2)
+        p_lw, p_lb, p_w1, p_w2 = ctx.params
+        gw1, d1 = grad_slot(p_w1)
+        gw2, d2 = grad_slot(p_w2)
+        glw, d3 = grad_slot(p_lw)
+        glb, d4 = grad_slot(p_lb)
         dg = dgrad(dyb, sh["w2"], M, dim, Ip, out_dtype=BF16)
-        dw2p = wgrad(dyb, g, dim, Ip, M)
+        wgrad(dyb, g, dim, I, M, out=gw2)                          # g's zero pad columns I..Ip-1 are simply not produced
         dh = torch.empty_like(h)
         hip.geglu_bwd(dg, h, dh, M, Ip, Ip, 2 * Ip)
         dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim)
-        dw1p = wgrad(dh, n2, 2 * Ip, dim, M)
+        wgrad(dh, n2, I, dim, M, out=gw1[:I])                      # value half  (rows 0..I-1 of the reference weight)
+        wgrad(dh[:, Ip:], n2, I, dim, M, out=gw1[I:])              # gate half   (rows I..2I-1)
         dx = torch.empty(M, dim, dtype=F32, device=dy.device)
-        dlw = torch.zeros_like(ln_w)
-        dlb = torch.zeros_like(ln_w)
-        hip.layernorm_bwd(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, dx, None, dlw, dlb, M, dim)
-        dw1 = torch.cat((dw1p[:I], dw1p[Ip:Ip + I]), 0)
-        dw2 = dw2p[:, :I].contiguous()
-        return dx.reshape(dy.shape), dlw, dlb, dw1, dw2, None, None
+        hip.layernorm_bwd(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, dx, None, glw, glb, M, dim)
+        return dx.reshape(dy.shape), _ret(glw, d3), _ret(glb, d4), _ret(gw1, d1), _ret(gw2, d2), None, None
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -406,6 +443,7 @@ class PatchEmbedFn(Function):
         _, y, mean2, rstd2 = layernorm(z, ln2w.detach(), ln2b.detach(), 1e-5, want16=False, want32=True)
         ctx.save_for_backward(vol, A, mean1, rstd1, z, mean2, rstd2, ln2w)
         ctx.sh, ctx.geom, ctx.dims = sh, geom, (B, C, Dz, Hy, Wx, F_, ldA, dim, M)
+        ctx.params = (ln1w, ln1b, w, b, ln2w, ln2b)
         return y.reshape(B, t, h, wt, dim)
 
     @staticmethod
@@ -416,18 +454,21 @@ class PatchEmbedFn(Function):
         B, C, Dz, Hy, Wx, F_, ldA, dim, M = ctx.dims
         dev = dy.device
         dy2 = _c(dy).reshape(M, dim)
+        p_l1w, p_l1b, p_w, p_b, p_l2w, p_l2b = ctx.params
         dz = torch.empty(M, dim, dtype=F32, device=dev)
         dzb = torch.empty(M, dim, dtype=BF16, device=dev)
-        d2w = torch.zeros(dim, dtype=F32, device=dev)
-        d2b = torch.zeros(dim, dtype=F32, device=dev)
+        d2w, k1 = grad_slot(p_l2w)
+        d2b, k2 = grad_slot(p_l2b)
         hip.layernorm_bwd(dy2, z, ln2w, mean2, rstd2, None, dz, dzb, d2w, d2b, M, dim)
-        db = colsum(dz)
-        dwp = wgrad(dzb, A, dim, ldA, M)
+        db, k3 = grad_slot(p_b)
+        colsum(dz, out=db)
+        dw, k4 = grad_slot(p_w)
+        wgrad(dzb, A, dim, F_, M, out=dw)
         dA = dgrad(dzb, sh["w"], M, dim, ldA, out_dtype=BF16)
-        d1w = torch.zeros(F_, dtype=F32, device=dev)
-        d1b = torch.zeros(F_, dtype=F32, device=dev)
+        d1w, k5 = grad_slot(p_l1w)
+        d1b, k6 = grad_slot(p_l1b)
         hip.patch_ln_bwd(vol, int(vol.dtype == BF16), dA, ldA, mean1, rstd1, d1w, d1b, B, C, Dz, Hy, Wx, tpatch, patch)
-        return None, d1w, d1b, dwp[:, :F_].contiguous(), db, d2w, d2b, None, None
+        return None, _ret(d1w, k5), _ret(d1b, k6), _ret(dw, k4), _ret(db, k3), _ret(d2w, k1), _ret(d2b, k2), None, None
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -473,10 +514,10 @@ class VQFn(Function):
             ctx.aux = (x2, inv)
             return quant.reshape(b, n, d), idx.reshape(b, n)
         ncodes = embed16.shape[0]
-        ncand = 4 * ((ncodes + 127) // 128)                      # top-2 of every 64-code slab
+        ncand = 16                                                # top-4 of each of 4 disjoint quarters of the codebook
         pv = torch.empty(M, ncand, dtype=F32, device=x.device)
         pi = torch.empty(M, ncand, dtype=torch.int32, device=x.device)
-        hip.gemm_argmax_partial(embed16, xn16, pv, pi, ncodes, M, d, embed16.stride(0), xn16.stride(0))
+        hip.vq_topk(embed16, xn16, pv, pi, ncodes, M, d, embed16.stride(0), xn16.stride(0))
         idx = torch.empty(M, dtype=torch.long, device=x.device)
         quant = torch.empty(M, d, dtype=F32, device=x.device)
         # 2^-7: twice the worst-case bf16 rounding error of a unit-vector dot product -> exact f32 arg-max

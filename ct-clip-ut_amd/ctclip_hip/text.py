@@ -39,6 +39,7 @@ class BertEmbedFn(Function):
         _, y, mean, rstd = ops.layernorm(e, lnw.detach(), lnb.detach(), eps, want16=False, want32=True)
         ctx.save_for_backward(ids_c, tt_c if tt_c is not None else ids_c.new_empty(0), e, mean, rstd, lnw)
         ctx.dims = (B, L, Hd, word.shape[0], pos.shape[0], type_.shape[0])
+        ctx.params = (word, pos, type_, lnw, lnb)
         return y
 
     @staticmethod
@@ -47,14 +48,17 @@ class BertEmbedFn(Function):
         B, L, Hd, nw, npos, nt = ctx.dims
         rows = B * L
         dev = dy.device
+        p_word, p_pos, p_type, p_lw, p_lb = ctx.params
         de = torch.empty(rows, Hd, dtype=F32, device=dev)
-        dlw, dlb = torch.zeros(Hd, dtype=F32, device=dev), torch.zeros(Hd, dtype=F32, device=dev)
+        dlw, k1 = ops.grad_slot(p_lw)
+        dlb, k2 = ops.grad_slot(p_lb)
         hip.layernorm_bwd(ops._c(dy), e, lnw, mean, rstd, None, de, None, dlw, dlb, rows, Hd)
-        dword = torch.zeros(nw, Hd, dtype=F32, device=dev)
-        dpos = torch.zeros(npos, Hd, dtype=F32, device=dev)
-        dtype_ = torch.zeros(nt, Hd, dtype=F32, device=dev)
+        dword, k3 = ops.grad_slot(p_word)                 # 30522 x 768: scatter-add straight into the arena
+        dpos, k4 = ops.grad_slot(p_pos)
+        dtype_, k5 = ops.grad_slot(p_type)
         hip.bert_embed_bwd(ids, tt if tt.numel() else None, de, dword, dpos, dtype_, rows, L, Hd)
-        return None, None, dword, dpos, dtype_, dlw, dlb, None
+        r = ops._ret
+        return None, None, r(dword, k3), r(dpos, k4), r(dtype_, k5), r(dlw, k1), r(dlb, k2), None
 
 
 class BertLayerFn(Function):
@@ -82,11 +86,59 @@ class BertLayerFn(Function):
         _, x2, mean2, rstd2 = ops.layernorm(o2, p[14].detach(), p[15].detach(), eps, want16=False, want32=True)
         ctx.save_for_backward(xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, p[8], p[14],
                               mask_add if mask_add is not None else x.new_empty(0))
-        ctx.sh, ctx.cfg = sh, cfg
+        ctx.sh, ctx.cfg, ctx.params = sh, cfg, p
         return x2
 
     @staticmethod
     def backward(ctx, dy):
+        xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, l1w, l2w, mask_add = ctx.saved_tensors
+        sh = ctx.sh
+        B, L, heads, dh, dp, eps = ctx.cfg
+        M, Hd = a.shape
+        inner, I = heads * dp, sh["inter"]
+        dev = dy.device
+        if mask_add.numel() == 0:
+            mask_add = None
+        p = ctx.params
+        if dp != dh:
+            return BertLayerFn._backward_padded(ctx, dy)
+        G = [ops.grad_slot(t) for t in p]                  # param-shaped accumulate buffers (.grad when pre-bound)
+        g = [b for b, _ in G]
+        # output LayerNorm
+        do2 = torch.empty(M, Hd, dtype=F32, device=dev)
+        do2b = torch.empty(M, Hd, dtype=BF16, device=dev)
+        hip.layernorm_bwd(ops._c(dy), o2, l2w, mean2, rstd2, None, do2, do2b, g[14], g[15], M, Hd)
+        ops.colsum(do2, out=g[13])
+        dm = ops.dgrad(do2b, sh["wo"], M, Hd, I, out_dtype=BF16)
+        ops.wgrad(do2b, m, Hd, I, M, out=g[12])
+        dh_ = torch.empty_like(hpre)
+        hip.gelu_bwd(dm, hpre, dh_, hpre.numel())
+        ops.colsum(dh_, out=g[11])
+        dx1 = ops.dgrad(dh_, sh["wi"], M, I, Hd, resid=do2)
+        ops.wgrad(dh_, x1_16, I, Hd, M, out=g[10])
+        # attention-output LayerNorm
+        da = torch.empty(M, Hd, dtype=F32, device=dev)
+        dab = torch.empty(M, Hd, dtype=BF16, device=dev)
+        hip.layernorm_bwd(dx1, a, l1w, mean1, rstd1, None, da, dab, g[8], g[9], M, Hd)
+        ops.colsum(da, out=g[7])
+        do = ops.dgrad(dab, sh["wao"], M, Hd, inner, out_dtype=BF16)
+        ops.wgrad(dab, o, Hd, inner, M, out=g[6])
+        dqkv = torch.empty(M, 3 * inner, dtype=BF16, device=dev)
+        delta = torch.empty(B, heads, L, dtype=F32, device=dev)
+        hip.attn_bwd(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, do, lse, delta, dqkv, dqkv[:, inner:],
+                     dqkv[:, 2 * inner:], None, mask_add, None, None, None, 0, 0, 0, B, L, heads, dp,
+                     3 * inner, 3 * inner, 3 * inner, inner, inner, 3 * inner, 3 * inner, 3 * inner,
+                     1.0 / math.sqrt(dh))
+        for j in range(3):                                  # query / key / value: weight and bias
+            part = dqkv[:, j * inner:(j + 1) * inner]
+            ops.colsum(part, out=g[2 * j + 1])
+            ops.wgrad(part, xb, inner, Hd, M, out=g[2 * j])
+        dx = ops.dgrad(dqkv, sh["wqkv"], M, 3 * inner, Hd, resid=da)
+        return (dx, None, None, None) + tuple(ops._ret(b, d) for b, d in G)
+
+    @staticmethod
+    def _backward_padded(ctx, dy):
+        """Head dims below 32 (toy configs): kernels run on zero-padded heads, gradients are un-padded afterwards."""
         xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, l1w, l2w, mask_add = ctx.saved_tensors
         sh = ctx.sh
         B, L, heads, dh, dp, eps = ctx.cfg

@@ -38,6 +38,10 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
  * search, ctvit.py:118 (library vector_quantize_pytorch, cosine-sim codebook). */
 int ctclip_gemm_argmax_partial(const void* A, const void* B, float* part_val, int* part_idx,
                                int M, int N, int K, long lda, long ldb, void* stream);
+/* same search, one workgroup per 128 columns sweeping all rows with a running per-lane top-4: part_val/part_idx are
+ * [N][16] (top-4 of each of 4 disjoint row subsets).  This is the variant the VQ module uses. */
+int ctclip_vq_topk(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda, long ldb,
+                   void* stream);
 
 /* ---- LayerNorm: attention.py:27-34 (beta==NULL), attention.py:46, ctvit.py:51, BertLayerNorm ---- */
 int ctclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,

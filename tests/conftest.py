@@ -12,6 +12,8 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# widen the dispatch gate of the pipelined GEMM so its ragged / split-K / transposed-operand paths are exercised
+os.environ.setdefault("CTCLIP_GEMM_V2_ALL", "1")
 
 
 def pytest_configure(config):

@@ -61,6 +61,29 @@ def test_gemm_layouts(hip, akm, bkm, M, N, K):
     check(f"gemm bf16 ({akm},{bkm})", C16, ref, 1e-2)
 
 
+@pytest.mark.parametrize("akm,bkm", [(1, 1), (1, 0), (0, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K,split", [(4096, 1536, 256, 1), (4000, 1496, 192, 1), (520, 392, 8192, 16), (3000, 640, 64, 1)])
+def test_gemm_pipelined_variant(hip, akm, bkm, M, N, K, split):
+    """Shapes large enough (and K % 64 == 0) to dispatch to the LDS-DMA pipelined kernel (csrc/gemm2.hip), including
+    ragged M/N tiles, the one-k-tile case, and split-K accumulation.  CTCLIP_GEMM_V2_ALL is set by conftest for the gpu
+    session so the gate is wide open here; the (1,1) long-K case goes there by default."""
+    A = bf(rnd(M, K, seed=1)) if akm else bf(rnd(K, M, seed=1))
+    B = bf(rnd(N, K, seed=2)) if bkm else bf(rnd(K, N, seed=2))
+    ref = (A.float() if akm else A.float().t()) @ (B.float().t() if bkm else B.float())
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    if split > 1:
+        C = res.clone()
+        hip.gemm_bf16(A, B, C, bias, None, M, N, K, A.stride(0), B.stride(0), N, 0, akm, bkm, 1, split, 1, 1.0, 0)
+        check(f"gemm2 split-k ({akm},{bkm})", C, ref + bias + res, 2e-3)
+        return
+    C = torch.empty(M, N, device=DEV)
+    hip.gemm_bf16(A, B, C, bias, res, M, N, K, A.stride(0), B.stride(0), N, N, akm, bkm, 1, 1, 0, 1.0, 0)
+    check(f"gemm2 f32+bias+res ({akm},{bkm}) {M}x{N}x{K}", C, ref + bias + res, 2e-3)
+    C16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16(A, B, C16, None, None, M, N, K, A.stride(0), B.stride(0), N, 0, akm, bkm, 0, 1, 0, 1.0, 1)
+    check(f"gemm2 bf16 gelu ({akm},{bkm})", C16, torch.nn.functional.gelu(ref), 1e-2)
+
+
 def test_gemm_mfma_orientation_asymmetric(hip):
     """A = I with an asymmetric B catches a transposed C write (guide: 'always A=I-check')."""
     n = 128
@@ -123,6 +146,15 @@ def test_gemm_argmax_partial_and_exact_select(hip):
     assert float((idx == ref).float().mean()) >= 0.995
     assert torch.equal(idx[:3].cpu(), torch.tensor([70, 201, 3]))
     assert torch.equal(quant, Ef[idx])
+    # the sweep variant used by the VQ module: 16 candidates per token
+    pv2 = torch.full((T, 16), float("nan"), device=DEV)
+    pi2 = torch.full((T, 16), -1, device=DEV, dtype=torch.int32)
+    hip.vq_topk(E, X, pv2, pi2, C_, T, K, K, K)
+    idx2 = torch.empty(T, dtype=torch.long, device=DEV)
+    hip.vq_select(pv2, pi2, 16, Xraw, inv, Ef, idx2, quant, T, K, 2.0 ** -7)
+    gap2 = exact.max(dim=1).values - exact.gather(1, idx2[:, None])[:, 0]
+    assert float(gap2.max()) <= 2e-7 and torch.equal(idx2[:3].cpu(), torch.tensor([70, 201, 3]))
+    assert float((idx2 == ref).float().mean()) >= 0.995
 
 
 # ---------------------------------------------------------------------------------------------- norms
