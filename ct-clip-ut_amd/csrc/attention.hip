@@ -289,9 +289,8 @@ __global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_bwd_dq_kernel(AttnAr
     dsum += __shfl_xor(dsum, 32, 64);
     if (valid && half == 0) a.delta[stat] = dsum;
     const float lse = a.lse[stat];
-    const int qoff = (a.grid_w > 0)
-                         ? (qrow_c / a.grid_w + a.grid_h - 1) * (2 * a.grid_w - 1) + (qrow_c % a.grid_w + a.grid_w - 1)
-                         : 0;
+    const int xq = (a.grid_w > 0) ? qrow_c % a.grid_w : 0;
+    const int qoff = (a.grid_w > 0) ? (qrow_c / a.grid_w + a.grid_h - 1) * (2 * a.grid_w - 1) + (xq + a.grid_w - 1) : 0;
 
     f32x16 dqacc[DT];
 #pragma unroll
@@ -332,15 +331,36 @@ __global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_bwd_dq_kernel(AttnAr
         const float p = valid ? __expf(s[i] - lse) : 0.f;  // -inf scores -> 0
         s[i] = p * (dp[i] - dsum);                          // dS^T[key][q]
       }
-      if (valid && a.dbias_table && a.grid_w > 0) {
+      if (a.dbias_table && a.grid_w > 0 && (a.grid_w & 3) == 0) {
+        // d(table)[idx(q,key)] += dS.  LDS float atomics are slow (~150 cycles per wave-instruction, measured), so
+        // contributions that share a table entry are summed across lanes first: idx(q+1, key+1) == idx(q, key) while q
+        // and key stay inside their image rows, so for each group of 4 consecutive keys (never straddling a key row:
+        // grid_w % 4 == 0) lane L collects element j from lane L+j -- one full-width atomic per group instead of four.
+        // Elements whose collector does not exist (wave edge / start of an image row) are added by their owner.
+        const int L = lane & 31;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int k0 = kt + 8 * g4 + 4 * half;
-          const int4 ko = *(const int4*)(keyoff + k0);
-          const int kk[4] = {ko.x, ko.y, ko.z, ko.w};
+          if (k0 >= a.n) continue;
+          const int base = qoff - keyoff[k0];
+          float u = s[4 * g4];
+#pragma unroll
+          for (int j = 1; j < 4; ++j) {
+            const float other = __shfl_down(s[4 * g4 + j], j, 32);
+            if (L + j < 32 && xq + j < a.grid_w) u += other;
+          }
+          if (valid) atomicAdd(&table[base], u);
+#pragma unroll
+          for (int j = 1; j < 4; ++j)
+            if (valid && (L < j || xq < j)) atomicAdd(&table[base - j], s[4 * g4 + j]);
+        }
+      } else if (valid && a.dbias_table && a.grid_w > 0) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int k0 = kt + 8 * g4 + 4 * half;
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (k0 + i < a.n) atomicAdd(&table[qoff - kk[i]], s[4 * g4 + i]);
+            if (k0 + i < a.n) atomicAdd(&table[qoff - keyoff[k0 + i]], s[4 * g4 + i]);
         }
       } else if (valid && (a.dbias_dense || a.dbias_table)) {
 #pragma unroll

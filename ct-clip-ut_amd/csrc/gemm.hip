@@ -439,12 +439,10 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
     // register-staged 128x128 kernel below (two workgroups per CU overlap one tile's epilogue with another's main loop;
     // tools/bench_gemm.py, profiles/r01_gemm_v1_v2.txt), so they stay here.  CTCLIP_GEMM_V2_ALL=1 widens the gate.
     static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
-    if (!force_v1 && v2_all && (K % 64) == 0 && blocks2 >= 192)
-      return ctclip_gemm2_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, a_kmajor, b_kmajor, c_fp32, split_k,
-                                 accumulate, alpha, act, (hipStream_t)stream);
     static const bool force_v1 = getenv("CTCLIP_GEMM_V1") != nullptr;
     const long blocks2 = (long)((M + 255) / 256) * ((N + 127) / 128) * (split_k > 1 ? split_k : 1);
-    if (!force_v1 && (K % 64) == 0 && blocks2 >= 192 && a_kmajor && b_kmajor && K >= 2048 && split_k <= 1)
+    const bool eligible = !force_v1 && (K % 64) == 0 && blocks2 >= 192;
+    if (eligible && (v2_all || (a_kmajor && b_kmajor && K >= 2048 && split_k <= 1)))
       return ctclip_gemm2_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, a_kmajor, b_kmajor, c_fp32, split_k,
                                  accumulate, alpha, act, (hipStream_t)stream);
   }

@@ -219,6 +219,7 @@ def attn_ref(q, k, v, bias, mask, scale):
     (3, 576, 8, 32, True, False),      # CT-ViT spatial
     (40, 24, 8, 32, False, False),     # CT-ViT temporal
     (4, 128, 12, 64, False, True),     # BERT L=128
+    (2, 128, 2, 32, True, False),      # 8 x 16 position grid: image rows wrap inside a 32-query tile
     (2, 40, 2, 32, True, False),       # ragged: n not a multiple of 32
     (2, 6, 4, 32, True, True),         # n % 4 != 0
     (1, 512, 2, 64, False, True),      # BERT L=512 (128 KiB of LDS)
