@@ -116,6 +116,172 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_kernel(const TIN* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fast path (the production geometry: p even, rows of tpb*p voxels a whole number of 16-byte vectors):
+//   phase 1  16-byte coalesced global loads straight into an LDS image kept in VOLUME order  buf[c*pt*p1 row][tpb*p2]
+//            (each voxel read from HBM exactly once, no per-element index arithmetic);
+//   phase 2  two-pass mean / rstd per tubelet, one wave per tubelet, 8-byte LDS reads;
+//   phase 3  the einops permutation happens on the LDS READ side: feature pair (f, f+1) = buf[f / p][tok*p + f % p],
+//            normalised, scaled, packed to bf16 and written as 16-byte coalesced rows of the GEMM operand.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int PF_THREADS = 512;
+
+template <typename TIN>
+__device__ __forceinline__ void load_block_vec(char* buf, const TIN* __restrict__ vol, const PatchGeom& g, int b, int t,
+                                               int h, int w0, int tid) {
+  const int nrows = g.C * g.pt * g.p;
+  const int vpr = (g.tpb * g.p * (int)sizeof(TIN)) / 16;               // 16-byte vectors per row
+  for (int e = tid; e < nrows * vpr; e += PF_THREADS) {
+    const int rowid = e / vpr, v = e - rowid * vpr;
+    const int c = rowid / (g.pt * g.p), rem = rowid - c * g.pt * g.p;
+    const int pti = rem / g.p, p1i = rem - pti * g.p;
+    const long src = ((((long)b * g.C + c) * g.Dz + t * g.pt + pti) * g.Hy + h * g.p + p1i) * g.Wx + (long)w0 * g.p;
+    *(uint4*)(buf + (size_t)e * 16) = *(const uint4*)((const char*)(vol + src) + v * 16);
+  }
+}
+
+template <typename TIN>
+__device__ __forceinline__ float2 ld_pair(const char* buf, int rlb, int rowid, int col);
+template <>
+__device__ __forceinline__ float2 ld_pair<bf16_t>(const char* buf, int rlb, int rowid, int col) {
+  const uint32_t w = *(const uint32_t*)(buf + (size_t)rowid * rlb + col * 2);
+  return make_float2(__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u));
+}
+template <>
+__device__ __forceinline__ float2 ld_pair<float>(const char* buf, int rlb, int rowid, int col) {
+  return *(const float2*)(buf + (size_t)rowid * rlb + col * 4);
+}
+
+template <typename TIN>
+__device__ __forceinline__ void block_stats(const char* buf, const PatchGeom& g, float* smean, float* srstd, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, nw = PF_THREADS / 64;
+  const int nrows = g.C * g.pt * g.p, rlb = g.tpb * g.p * (int)sizeof(TIN);
+  for (int tok = wave; tok < g.tpb; tok += nw) {
+    float s = 0.f;
+    for (int r = lane; r < nrows; r += 64)
+      for (int c2 = 0; c2 < g.p; c2 += 2) { const float2 v = ld_pair<TIN>(buf, rlb, r, tok * g.p + c2); s += v.x + v.y; }
+    const float mu = wave_sum(s) / (float)g.F;
+    float q = 0.f;
+    for (int r = lane; r < nrows; r += 64)
+      for (int c2 = 0; c2 < g.p; c2 += 2) {
+        const float2 v = ld_pair<TIN>(buf, rlb, r, tok * g.p + c2);
+        q += (v.x - mu) * (v.x - mu) + (v.y - mu) * (v.y - mu);
+      }
+    const float rs = rsqrtf(wave_sum(q) / (float)g.F + g.eps);
+    if (lane == 0) { smean[tok] = mu; srstd[tok] = rs; }
+  }
+}
+
+template <typename TIN>
+__global__ __launch_bounds__(PF_THREADS) void patch_ln_fwd_fast(const TIN* __restrict__ vol, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, bf16_t* __restrict__ A,
+                                                               float* __restrict__ mean, float* __restrict__ rstd, PatchGeom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nrows = g.C * g.pt * g.p, rlb = g.tpb * g.p * (int)sizeof(TIN);
+  char* buf = smem;
+  float* smean = (float*)(smem + (size_t)nrows * rlb);
+  float* srstd = smean + g.tpb;
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int wg = bid % g.wgroups; bid /= g.wgroups;
+  const int h = bid % g.Ht; bid /= g.Ht;
+  const int t = bid % g.Tt;
+  const int b = bid / g.Tt;
+  const int w0 = wg * g.tpb;
+  load_block_vec<TIN>(buf, vol, g, b, t, h, w0, tid);
+  __syncthreads();
+  block_stats<TIN>(buf, g, smean, srstd, tid);
+  __syncthreads();
+  const long row0 = (((long)b * g.Tt + t) * g.Ht + h) * g.Wt + w0;
+  if (tid < g.tpb) { mean[row0 + tid] = smean[tid]; rstd[row0 + tid] = srstd[tid]; }
+  const int cpt = (int)(g.ldA >> 3);                                    // 16-byte output chunks per tubelet row
+  for (int e = tid; e < g.tpb * cpt; e += PF_THREADS) {
+    const int tok = e / cpt, f0 = (e - tok * cpt) * 8;
+    const float mu = smean[tok], rs = srstd[tok];
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const int f = f0 + k;
+      if (f < g.F) {
+        const int rowid = f / g.p, c2 = f - rowid * g.p;
+        const float2 v = ld_pair<TIN>(buf, rlb, rowid, tok * g.p + c2);
+        o[k] = (v.x - mu) * rs * gamma[f] + beta[f];
+        o[k + 1] = (v.y - mu) * rs * gamma[f + 1] + beta[f + 1];
+      } else { o[k] = 0.f; o[k + 1] = 0.f; }
+    }
+    uint4 pk;
+    pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
+    *(uint4*)(A + (row0 + tok) * g.ldA + f0) = pk;
+  }
+}
+
+// dgamma / dbeta of the first LayerNorm.  A workgroup walks `hgroup` consecutive (b,t,h) slabs (both w halves of each),
+// every thread owning fixed feature pairs, so the atomics are issued once per workgroup instead of once per slab.
+template <typename TIN>
+__global__ __launch_bounds__(PF_THREADS) void patch_ln_bwd_fast(const TIN* __restrict__ vol, const bf16_t* __restrict__ dA, long ldd,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               PatchGeom g, int hgroup) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nrows = g.C * g.pt * g.p, rlb = g.tpb * g.p * (int)sizeof(TIN);
+  char* buf = smem;
+  const int tid = threadIdx.x;
+  constexpr int MAXP = 4;                                               // feature pairs per thread: F <= 2*4*512 = 4096
+  float ag[MAXP][2], ab[MAXP][2];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) { ag[i][0] = ag[i][1] = ab[i][0] = ab[i][1] = 0.f; }
+  const long slab0 = (long)blockIdx.x * hgroup;
+  const long nslabs = (long)g.B * g.Tt * g.Ht;
+  for (long sl = slab0; sl < slab0 + hgroup && sl < nslabs; ++sl) {
+    const int h = (int)(sl % g.Ht);
+    const int t = (int)((sl / g.Ht) % g.Tt);
+    const int b = (int)(sl / ((long)g.Ht * g.Tt));
+    for (int wg = 0; wg < g.wgroups; ++wg) {
+      const int w0 = wg * g.tpb;
+      __syncthreads();
+      load_block_vec<TIN>(buf, vol, g, b, t, h, w0, tid);
+      __syncthreads();
+      const long row0 = (((long)b * g.Tt + t) * g.Ht + h) * g.Wt + w0;
+#pragma unroll
+      for (int i = 0; i < MAXP; ++i) {
+        const int f = (i * PF_THREADS + tid) * 2;
+        if (f >= g.F) continue;
+        const int rowid = f / g.p, c2 = f - rowid * g.p;
+        for (int tok = 0; tok < g.tpb; ++tok) {
+          const uint32_t dw = *(const uint32_t*)(dA + (row0 + tok) * ldd + f);
+          const float d0 = __uint_as_float(dw << 16), d1 = __uint_as_float(dw & 0xffff0000u);
+          const float mu = mean[row0 + tok], rs = rstd[row0 + tok];
+          const float2 v = ld_pair<TIN>(buf, rlb, rowid, tok * g.p + c2);
+          ag[i][0] += d0 * (v.x - mu) * rs; ag[i][1] += d1 * (v.y - mu) * rs;
+          ab[i][0] += d0; ab[i][1] += d1;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int f = (i * PF_THREADS + tid) * 2;
+    if (f >= g.F) continue;
+    atomicAdd(dgamma + f, ag[i][0]); atomicAdd(dgamma + f + 1, ag[i][1]);
+    atomicAdd(dbeta + f, ab[i][0]); atomicAdd(dbeta + f + 1, ab[i][1]);
+  }
+}
+
+// fast-path eligibility + geometry: tpb must divide Wt and give whole 16-byte vectors per row
+bool fast_geom(PatchGeom& g, const void* vol, size_t esz, size_t* lds) {
+  if ((g.p & 1) || (g.F & 7) || (g.F > 4096) || ((uintptr_t)vol & 15) || (((size_t)g.Wx * esz) & 15)) return false;
+  const int nrows = g.C * g.pt * g.p;
+  for (int tpb = g.Wt; tpb >= 1; --tpb) {
+    if (g.Wt % tpb) continue;
+    const size_t rlb = (size_t)tpb * g.p * esz;
+    if ((rlb & 15) || nrows * rlb > 128 * 1024) continue;
+    g.tpb = tpb; g.wgroups = g.Wt / tpb;
+    *lds = ((nrows * rlb + (size_t)tpb * 8 + 15) & ~(size_t)15);
+    return true;
+  }
+  return false;
+}
+
 int make_geom(PatchGeom& g, int B, int C, int Dz, int Hy, int Wx, int pt, int p, long ldA, float eps, int in_bf16,
               size_t* lds) {
   if (pt <= 0 || p <= 0 || Dz % pt || Hy % p || Wx % p) return (int)hipErrorInvalidValue;
@@ -142,6 +308,23 @@ int ctclip_patch_ln_fwd(const void* volume, int volume_is_bf16, const float* gam
   PatchGeom g{};
   size_t lds = 0;
   if (int e = make_geom(g, B, C, Dz, Hy, Wx, pt, p, ldA, eps, volume_is_bf16, &lds)) return e;
+  {
+    PatchGeom gf = g;
+    size_t ldsf = 0;
+    if (fast_geom(gf, volume, volume_is_bf16 ? 2 : 4, &ldsf) && (((uintptr_t)A_bf16) & 15) == 0) {
+      const unsigned nb = (unsigned)((long)B * gf.Tt * gf.Ht * gf.wgroups);
+      if (volume_is_bf16) {
+        if (ldsf > 65536) hipFuncSetAttribute((const void*)patch_ln_fwd_fast<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+        hipLaunchKernelGGL(patch_ln_fwd_fast<bf16_t>, dim3(nb), dim3(PF_THREADS), ldsf, (hipStream_t)stream,
+                           (const bf16_t*)volume, gamma, beta, (bf16_t*)A_bf16, mean, rstd, gf);
+      } else {
+        if (ldsf > 65536) hipFuncSetAttribute((const void*)patch_ln_fwd_fast<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+        hipLaunchKernelGGL(patch_ln_fwd_fast<float>, dim3(nb), dim3(PF_THREADS), ldsf, (hipStream_t)stream,
+                           (const float*)volume, gamma, beta, (bf16_t*)A_bf16, mean, rstd, gf);
+      }
+      CTCLIP_CHECK_LAUNCH();
+    }
+  }
   const unsigned nblk = (unsigned)((long)B * g.Tt * g.Ht * g.wgroups);
   if (volume_is_bf16) {
     if (lds > 65536) hipFuncSetAttribute((const void*)patch_ln_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -162,6 +345,25 @@ int ctclip_patch_ln_bwd(const void* volume, int volume_is_bf16, const void* dA_b
   size_t lds = 0;
   const long F = (long)C * pt * p * p;
   if (int e = make_geom(g, B, C, Dz, Hy, Wx, pt, p, (F + 7) / 8 * 8, 0.f, volume_is_bf16, &lds)) return e;
+  {
+    PatchGeom gf = g;
+    size_t ldsf = 0;
+    if (fast_geom(gf, volume, volume_is_bf16 ? 2 : 4, &ldsf) && (ldd & 1) == 0 && (((uintptr_t)dA_bf16) & 3) == 0) {
+      const int hgroup = 4;
+      const long nslabs = (long)B * gf.Tt * gf.Ht;
+      const unsigned nb = (unsigned)((nslabs + hgroup - 1) / hgroup);
+      if (volume_is_bf16) {
+        if (ldsf > 65536) hipFuncSetAttribute((const void*)patch_ln_bwd_fast<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+        hipLaunchKernelGGL(patch_ln_bwd_fast<bf16_t>, dim3(nb), dim3(PF_THREADS), ldsf, (hipStream_t)stream,
+                           (const bf16_t*)volume, (const bf16_t*)dA_bf16, ldd, mean, rstd, dgamma, dbeta, gf, hgroup);
+      } else {
+        if (ldsf > 65536) hipFuncSetAttribute((const void*)patch_ln_bwd_fast<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+        hipLaunchKernelGGL(patch_ln_bwd_fast<float>, dim3(nb), dim3(PF_THREADS), ldsf, (hipStream_t)stream,
+                           (const float*)volume, (const bf16_t*)dA_bf16, ldd, mean, rstd, dgamma, dbeta, gf, hgroup);
+      }
+      CTCLIP_CHECK_LAUNCH();
+    }
+  }
   const unsigned nblk = (unsigned)((long)B * g.Tt * g.Ht * g.wgroups);
   if (volume_is_bf16) {
     if (lds > 65536) hipFuncSetAttribute((const void*)patch_ln_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
