@@ -434,15 +434,16 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
   if (split_k > 1 && !accumulate) return (int)hipErrorInvalidValue;
   if (accumulate && (!c_fp32 || (act & 0xff) != 0)) return (int)hipErrorInvalidValue;
   {
-    // Long-K k-major problems go to the pipelined 256x128 LDS-DMA kernel (gemm2.hip: 874-919 vs 748 TFLOP/s at
-    // 4096^3 / 8192^3).  The short-K (256..1408) and split-K shapes of the CT-CLIP step measured equal or faster on the
-    // register-staged 128x128 kernel below (two workgroups per CU overlap one tile's epilogue with another's main loop;
-    // tools/bench_gemm.py, profiles/r01_gemm_v1_v2.txt), so they stay here.  CTCLIP_GEMM_V2_ALL=1 widens the gate.
+    // k-major x k-major problems that are long in K (874-919 vs 748 TFLOP/s at 4096^3 / 8192^3) or very large in M*N
+    // (the forward projections at >= 16 pairs per GPU: FF1 605 vs 561, kv 609 vs 567 TFLOP/s) go to the pipelined
+    // 256x128 LDS-DMA kernel (gemm2.hip).  dgrad / wgrad (transposed-read operands, split-K) measured faster on the
+    // register-staged 128x128 kernel below, whose two workgroups per CU overlap one tile's epilogue with another's main
+    // loop (tools/bench_gemm.py, profiles/r01_gemm_v1_v2.txt).  CTCLIP_GEMM_V2_ALL=1 widens the gate (tests do).
     static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
     static const bool force_v1 = getenv("CTCLIP_GEMM_V1") != nullptr;
     const long blocks2 = (long)((M + 255) / 256) * ((N + 127) / 128) * (split_k > 1 ? split_k : 1);
     const bool eligible = !force_v1 && (K % 64) == 0 && blocks2 >= 192;
-    if (eligible && (v2_all || (a_kmajor && b_kmajor && K >= 2048 && split_k <= 1)))
+    if (eligible && (v2_all || (a_kmajor && b_kmajor && split_k <= 1 && (K >= 2048 || (long)M * N >= 100000000L))))
       return ctclip_gemm2_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, a_kmajor, b_kmajor, c_fp32, split_k,
                                  accumulate, alpha, act, (hipStream_t)stream);
   }

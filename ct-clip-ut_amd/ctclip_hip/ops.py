@@ -150,6 +150,20 @@ def _ret(buf, direct):
     return None if direct else buf
 
 
+def _tag16(t32, t16):
+    """Attach the bf16 copy a kernel produced for free to the f32 gradient it mirrors.  The next Function.backward picks
+    it up with _get16 instead of launching a cast kernel; the pointer check makes a stale or re-wrapped tensor harmless."""
+    t32._ctclip_bf16 = (t32.data_ptr(), t32.shape, t16)
+    return t32
+
+
+def _get16(t32):
+    tag = getattr(t32, "_ctclip_bf16", None)
+    if tag is not None and tag[0] == t32.data_ptr() and tag[1] == t32.shape and t32.is_contiguous():
+        return tag[2].reshape(-1, t32.shape[-1])
+    return cast16(_c(t32).reshape(-1, t32.shape[-1]))
+
+
 # ---------------------------------------------------------------------------------------------------
 # LayerNorm as a module-level op (Transformer.norm_out, patch-embed tail)
 # ---------------------------------------------------------------------------------------------------
@@ -169,10 +183,11 @@ class LayerNormFn(Function):
         gamma, beta = ctx.params
         dy2 = _c(dy).reshape(x2.shape)
         dx = torch.empty_like(x2)
+        dx16 = torch.empty(x2.shape, dtype=BF16, device=x2.device)
         dg, dg_d = grad_slot(gamma)
         db, db_d = grad_slot(beta) if beta is not None else (None, True)
-        hip.layernorm_bwd(dy2, x2, gamma.detach(), mean, rstd, None, dx, None, dg, db, x2.shape[0], x2.shape[1])
-        return dx.reshape(dy.shape), _ret(dg, dg_d), _ret(db, db_d), None
+        hip.layernorm_bwd(dy2, x2, gamma.detach(), mean, rstd, None, dx, dx16, dg, db, x2.shape[0], x2.shape[1])
+        return _tag16(dx.reshape(dy.shape), dx16), _ret(dg, dg_d), _ret(db, db_d), None
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -188,18 +203,22 @@ class PegFn(Function):
         xc = _c(x)
         w27 = weight.detach().reshape(d, 27).t().contiguous()
         y = torch.empty_like(xc)
-        hip.peg_fwd(xc, w27, bias.detach(), y, None, b, t, h, w, d, int(residual))
+        y16 = torch.empty(xc.shape, dtype=BF16, device=xc.device)      # the next op (attention) wants its input in bf16 too
+        hip.peg_fwd(xc, w27, bias.detach(), y, y16, b, t, h, w, d, int(residual))
         ctx.save_for_backward(xc, w27)
         ctx.geom = (b, t, h, w, d, int(residual))
-        return y
+        ctx.mark_non_differentiable(y16)
+        return y, y16
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dy16):
         xc, w27 = ctx.saved_tensors
         b, t, h, w, d, residual = ctx.geom
         dyc = _c(dy)
         dx = torch.empty_like(dyc)
-        hip.peg_bwd_data(dyc, w27, dx, None, b, t, h, w, d, residual)
+        dx16 = torch.empty(dyc.shape, dtype=BF16, device=dyc.device)
+        hip.peg_bwd_data(dyc, w27, dx, dx16, b, t, h, w, d, residual)
+        _tag16(dx, dx16)
         dw27 = torch.zeros(27, d, dtype=F32, device=dy.device)
         db = torch.zeros(d, dtype=F32, device=dy.device)
         hip.peg_bwd_weight(dyc, xc, dw27, db, b, t, h, w, d)
@@ -223,7 +242,8 @@ class AttentionFn(Function):
         inner = heads * dp
         x2 = _c(x).reshape(M, dim)
         n1, _, mean, rstd = layernorm(x2, gamma.detach(), None, 1e-5)
-        xb = cast16(x2)
+        x16 = aux.get("x16")
+        xb = x16.reshape(M, dim) if (x16 is not None and x16.numel() == M * dim and x16.is_contiguous()) else cast16(x2)
         q = gemm(n1, sh["wq"], M, inner, dim)
         kv = gemm(xb, sh["wkv"], M, 2 * inner, dim)               # QUIRK attention.py:138: kv from un-normalised x
         qh = torch.empty_like(q)
@@ -267,7 +287,7 @@ class AttentionFn(Function):
         if bias_dense.numel() == 0:
             bias_dense = None
         dy2 = _c(dy).reshape(M, dim)
-        dyb = cast16(dy2)
+        dyb = _get16(dy)
         do = dgrad(dyb, sh["wout"], M, dim, inner, out_dtype=BF16)
         dqh = torch.empty(M, inner, dtype=BF16, device=dev)
         dkh = torch.empty(M, inner, dtype=BF16, device=dev)
@@ -307,8 +327,9 @@ class AttentionFn(Function):
             wgrad(dq, n1, inner, dim, M, out=gwq)
             dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None)
             wgrad(dkv, xb, 2 * inner, dim, M, out=gwkv)
-            hip.layernorm_bwd(dn1, x2, gamma, mean, rstd, dxkv, dx, None, gg, None, M, dim)
-            return (dx.reshape(nseq, n, dim), _ret(gg, d6), _ret(gwq, d3), _ret(gwkv, d4), _ret(gqs, d1), _ret(gks, d2),
+            dx16 = torch.empty(M, dim, dtype=BF16, device=dev)
+            hip.layernorm_bwd(dn1, x2, gamma, mean, rstd, dxkv, dx, dx16, gg, None, M, dim)
+            return (_tag16(dx.reshape(nseq, n, dim), dx16), _ret(gg, d6), _ret(gwq, d3), _ret(gwkv, d4), _ret(gqs, d1), _ret(gks, d2),
                     _ret(gwo, d5), dbias, None, None, None)
         dwout = wgrad(dyb, o, dim, inner, M)
         dqs = torch.zeros(dp, dtype=F32, device=dev)
@@ -357,7 +378,7 @@ class FeedForwardFn(Function):
         M, dim = x2.shape
         I, Ip = sh["inner"], sh["inner_p"]
         dy2 = _c(dy).reshape(M, dim)
-        dyb = cast16(dy2)
+        dyb = _get16(dy)
         p_lw, p_lb, p_w1, p_w2 = ctx.params
         gw1, d1 = grad_slot(p_w1)
         gw2, d2 = grad_slot(p_w2)
@@ -371,8 +392,9 @@ class FeedForwardFn(Function):
         wgrad(dh, n2, I, dim, M, out=gw1[:I])                      # value half  (rows 0..I-1 of the reference weight)
         wgrad(dh[:, Ip:], n2, I, dim, M, out=gw1[I:])              # gate half   (rows I..2I-1)
         dx = torch.empty(M, dim, dtype=F32, device=dy.device)
-        hip.layernorm_bwd(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, dx, None, glw, glb, M, dim)
-        return dx.reshape(dy.shape), _ret(glw, d3), _ret(glb, d4), _ret(gw1, d1), _ret(gw2, d2), None, None
+        dx16 = torch.empty(M, dim, dtype=BF16, device=dy.device)
+        hip.layernorm_bwd(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, dx, dx16, glw, glb, M, dim)
+        return _tag16(dx.reshape(dy.shape), dx16), _ret(glw, d3), _ret(glb, d4), _ret(gw1, d1), _ret(gw2, d2), None, None
 
 
 # ---------------------------------------------------------------------------------------------------

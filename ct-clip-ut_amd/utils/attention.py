@@ -109,12 +109,13 @@ class PEG(nn.Module):
             raise NotImplementedError("non-causal PEG is not used by CT-ViT (ctvit.py:54-62 sets peg_causal=True)")
         if x.ndim == 3 and shape is None:
             raise ValueError("PEG needs `shape` for [b, n, d] input")
-        orig = x.shape
         if x.ndim == 5:
             shape = x.shape[:4]
-        y = ops.PegFn.apply(x.to(F32).reshape(*[int(s) for s in shape], x.shape[-1]), self.dsconv.weight,
-                            self.dsconv.bias, tuple(int(s) for s in shape), residual)
-        return y.reshape(orig)
+        # the Function works on flat memory and returns the input's shape: no view nodes in the autograd graph, so the
+        # bf16 gradient shadow tagged by its backward reaches the previous layer's backward intact
+        y, y16 = ops.PegFn.apply(x.to(F32), self.dsconv.weight, self.dsconv.bias, tuple(int(s) for s in shape), residual)
+        self._last_bf16 = y16                      # bf16 copy of the output, written by the same kernel (fused path only)
+        return y
 
 
 class PositionBias:
@@ -173,7 +174,7 @@ class Attention(nn.Module):
 
         return self._shadow.get("attn", (wq, wkv, wo, qs, ks), build)
 
-    def forward(self, x, mask=None, context=None, attn_bias=None, residual: bool = False):
+    def forward(self, x, mask=None, context=None, attn_bias=None, residual: bool = False, x16=None):
         _need_cuda(x, "Attention")
         if exists(context) or exists(mask) or self.num_null_kv > 0:
             raise NotImplementedError("cross-attention context / masks / null key-values are GenerateCT-only branches")
@@ -191,6 +192,7 @@ class Attention(nn.Module):
                    "grid": attn_bias.grid or (0, 0)}
         else:
             bias_t, aux = attn_bias, {"kind": "dense"}
+        aux["x16"] = x16                            # optional bf16 copy of x from the producing kernel (saves a cast pass)
         y, probs = ops.AttentionFn.apply(x.to(F32), self.norm.gamma, self.to_q.weight, self.to_kv.weight, self.q_scale,
                                          self.k_scale, self.to_out.weight, bias_t, self._shadows(), cfg, aux)
         return y, (probs if self.return_attn else None)
@@ -306,12 +308,18 @@ class Transformer(nn.Module):
             # Residual adds are fused into the kernels' epilogues unless someone hooked the sub-module
             # (attribution code hooks layers[i][1], visualizations.py:242-263): then the module is called the
             # reference way so hooks see the branch output.
+            x16 = None
             if exists(peg):
-                x = peg(x, shape=video_shape) + x if _hooked(peg) else peg.forward(x, shape=video_shape, residual=True)
+                if _hooked(peg):
+                    x = peg(x, shape=video_shape) + x
+                else:
+                    x = peg.forward(x, shape=video_shape, residual=True)
+                    x16 = peg._last_bf16
+                    peg._last_bf16 = None
             if _hooked(self_attn):
                 out, _w = self_attn(x, attn_bias=attn_bias)
                 x = out + x
             else:
-                x, _w = self_attn.forward(x, attn_bias=attn_bias, residual=True)
+                x, _w = self_attn.forward(x, attn_bias=attn_bias, residual=True, x16=x16)
             x = ff(x) + x if _hooked(ff) else ff.forward(x, residual=True)
         return self.norm_out(x)
