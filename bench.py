@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CTCLIP_BENCH_BATCH", 32)), help="pairs per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CTCLIP_BENCH_BATCH", 64)), help="pairs per GPU")
     ap.add_argument("--text-len", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--local-negatives", action="store_true", help="BASELINE config 3: no embedding all-gather")

@@ -197,24 +197,20 @@ __global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_fwd_kernel(AttnArgs 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) dst[ks] = gfrag(kbase + (long)(ok ? key : 0) * a.ldk, ks, lane, ok);
   };
-  float add_cur[16], add_nxt[16];
-  bf16x8 kf_cur[KS], kf_nxt[KS];
-  load_addend(add_cur, a, head, seq, qrow_c, 0, half);
-  load_k(kf_cur, 0);
+  // Prefetch without double buffers: each buffer is re-loaded for tile kt+32 immediately after its last use in tile
+  // kt, so the loads have the whole softmax + PV phase to land and the kernel stays under 96 VGPRs (2 workgroups/CU).
+  float add[16];
+  bf16x8 kf[KS];
+  load_addend(add, a, head, seq, qrow_c, 0, half);
+  load_k(kf, 0);
   for (int kt = 0; kt < a.n_pad; kt += 32) {
-    if (kt + 32 < a.n_pad) {
-      load_addend(add_nxt, a, head, seq, qrow_c, kt + 32, half);
-      load_k(kf_nxt, kt + 32);
-    }
     f32x16 s;
     zero_acc(s);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) s = mfma32(kf_cur[ks], qf[ks], s);
-    apply_scores(s, add_cur, a, kt, half);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) add_cur[i] = add_nxt[i];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf_cur[ks] = kf_nxt[ks];
+    for (int ks = 0; ks < KS; ++ks) s = mfma32(kf[ks], qf[ks], s);
+    if (kt + 32 < a.n_pad) load_k(kf, kt + 32);
+    apply_scores(s, add, a, kt, half);
+    if (kt + 32 < a.n_pad) load_addend(add, a, head, seq, qrow_c, kt + 32, half);
     float tmax = s[0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
@@ -251,7 +247,7 @@ __global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_fwd_kernel(AttnArgs 
 // backward pass 1: dQ, delta = rowsum(dO * O), d(bias)
 // ------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(D == 32 ? 384 : 256) void attn_bwd_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KS = D / 16, DT = D / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -304,28 +300,22 @@ __global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_bwd_dq_kernel(AttnAr
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) dst[ks] = gfrag(vbase + (long)(ok ? key : 0) * a.ldv, ks, lane, ok);
     };
-    float add_cur[16], add_nxt[16];
-    bf16x8 vf_cur[KS], vf_nxt[KS];
-    load_addend(add_cur, a, head, seq, qrow_c, 0, half);
-    load_v(vf_cur, 0);
+    float add[16];
+    bf16x8 vf[KS];
+    load_addend(add, a, head, seq, qrow_c, 0, half);
+    load_v(vf, 0);
     for (int kt = 0; kt < a.n_pad; kt += 32) {
-      if (kt + 32 < a.n_pad) {
-        load_addend(add_nxt, a, head, seq, qrow_c, kt + 32, half);
-        load_v(vf_nxt, kt + 32);
-      }
       f32x16 s, dp;
       zero_acc(s);
       zero_acc(dp);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         s = mfma32(row_frag<D>(kimg, kt, ks, lane), qf[ks], s);
-        dp = mfma32(vf_cur[ks], dof[ks], dp);
+        dp = mfma32(vf[ks], dof[ks], dp);
       }
-      apply_scores(s, add_cur, a, kt, half);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) add_cur[i] = add_nxt[i];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) vf_cur[ks] = vf_nxt[ks];
+      if (kt + 32 < a.n_pad) load_v(vf, kt + 32);          // re-load in place right after the last use
+      apply_scores(s, add, a, kt, half);
+      if (kt + 32 < a.n_pad) load_addend(add, a, head, seq, qrow_c, kt + 32, half);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float p = valid ? __expf(s[i] - lse) : 0.f;  // -inf scores -> 0
@@ -585,10 +575,11 @@ int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, 
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.scale = scale;
   if (int e = check(a, dhead)) return e;
-  const int nw = waves_for(n, dhead);
+  // both backward passes use 6-wave workgroups: two of them fit per CU at their register budgets (12 resident waves)
+  const int nw = waves_for(n, dhead, 6);
   dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
-  const int nw2 = waves_for(n, dhead, 6);   // dK/dV pass keeps 2x the accumulators: 6 waves -> 256-VGPR budget
-  dim3 grid2((a.n_pad / 32 + nw2 - 1) / nw2, heads, nseq), block2(nw2 * 64);
+  const int nw2 = nw;
+  dim3 grid2 = grid, block2 = block;
   const size_t lds1 = (size_t)a.n_pad * dhead * 2 +
                       (a.dbias_table ? (size_t)((table_size + 3) & ~3) * 4 + (size_t)a.n_pad * 4 : 0);
   const size_t lds2 = (size_t)a.n_pad * dhead * 4 + (size_t)a.n_pad * 8;

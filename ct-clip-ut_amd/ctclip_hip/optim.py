@@ -151,7 +151,7 @@ class GradSync:
             n = g.numel()
             for s in range(0, n, self.bucket_elems):
                 chunk = g[s:min(n, s + self.bucket_elems)]
-                if g.is_cuda:
+                if g.is_cuda and dist.get_backend(self.group) == "nccl":
                     handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
                 else:   # gloo (CPU tests) has no AVG
                     handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))

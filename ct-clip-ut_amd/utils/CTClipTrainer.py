@@ -41,14 +41,17 @@ class _Runtime:
     def __init__(self):
         self.distributed = dist.is_available() and dist.is_initialized()
         if not self.distributed and "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
-            dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo",
-                                    timeout=timedelta(seconds=36000))          # reference :65
+            # "nccl" is RCCL on ROCm (reference :65).  CTCLIP_DIST_BACKEND=gloo lets several ranks share one GPU for
+            # rehearsals of the multi-rank path (RCCL refuses duplicate devices).
+            backend = os.environ.get("CTCLIP_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+            dist.init_process_group(backend=backend, timeout=timedelta(seconds=36000))
             self.distributed = True
         self.process_index = dist.get_rank() if self.distributed else 0
         self.num_processes = dist.get_world_size() if self.distributed else 1
         local = int(os.environ.get("LOCAL_RANK", 0))
         if not torch.cuda.is_available():
             raise RuntimeError("CTClipTrainer: no HIP device visible; the training step has no CPU fallback")
+        local = local % max(1, torch.cuda.device_count())                     # shared-GPU rehearsal: ranks wrap around
         self.device = torch.device("cuda", local)
         torch.cuda.set_device(self.device)
         self.is_main_process = self.process_index == 0
