@@ -434,16 +434,16 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
   if (split_k > 1 && !accumulate) return (int)hipErrorInvalidValue;
   if (accumulate && (!c_fp32 || (act & 0xff) != 0)) return (int)hipErrorInvalidValue;
   {
-    // k-major x k-major problems that are long in K (874-919 vs 748 TFLOP/s at 4096^3 / 8192^3) or very large in M*N
-    // (the forward projections at >= 16 pairs per GPU: FF1 605 vs 561, kv 609 vs 567 TFLOP/s) go to the pipelined
-    // 256x128 LDS-DMA kernel (gemm2.hip).  dgrad / wgrad (transposed-read operands, split-K) measured faster on the
-    // register-staged 128x128 kernel below, whose two workgroups per CU overlap one tile's epilogue with another's main
-    // loop (tools/bench_gemm.py, profiles/r01_gemm_v1_v2.txt).  CTCLIP_GEMM_V2_ALL=1 widens the gate (tests do).
+    // Problems with K % 64 == 0 and enough 256x128 tiles to fill the chip go to the pipelined LDS-DMA kernel (gemm2.hip):
+    // 969/957 vs 748/750 TFLOP/s at 4096^3/8192^3; at 32 pairs/GPU FF1 forward 622 vs 561, FF1 wgrad 675 vs 526, kv wgrad
+    // 753 vs 470 (profiles/r01_gemm_v1_v2.txt).  Ragged-K (K % 8 == 0) and small problems (BERT at M = 128*B) stay on the
+    // register-staged 128x128 kernel below.  CTCLIP_GEMM_V2_ALL=1 lowers the size gate (the tests do, to cover every
+    // path with small shapes); CTCLIP_GEMM_V1=1 disables the pipelined kernel.
     static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
     static const bool force_v1 = getenv("CTCLIP_GEMM_V1") != nullptr;
     const long blocks2 = (long)((M + 255) / 256) * ((N + 127) / 128) * (split_k > 1 ? split_k : 1);
     const bool eligible = !force_v1 && (K % 64) == 0 && blocks2 >= 192;
-    if (eligible && (v2_all || (a_kmajor && b_kmajor && split_k <= 1 && (K >= 2048 || (long)M * N >= 100000000L))))
+    if (eligible || (v2_all && !force_v1 && (K % 64) == 0 && blocks2 >= 8))
       return ctclip_gemm2_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, a_kmajor, b_kmajor, c_fp32, split_k,
                                  accumulate, alpha, act, (hipStream_t)stream);
   }

@@ -38,20 +38,36 @@ __device__ __forceinline__ uint32_t tile_off(int rk, int chunk) {
   return (uint32_t)(rk * 256 + ((chunk ^ (((rk & 3) << 2) | ((rk >> 2) & 3))) << 4));
 }
 
-template <bool KM>
-__device__ __forceinline__ bf16x8 read_frag(const char* tile, int rbase, int s, int lane) {
-  if (KM) {
-    const int r = rbase + (lane & 31);
-    return *(const bf16x8*)(tile + tile_off<true>(r, 2 * s + (lane >> 5)));
-  } else {
-    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3, h = g >> 1;
-    const int m0 = rbase + 16 * (g & 1) + 4 * p;
-    const int klo = 16 * s + 8 * h + q;
-    const uint32_t sub = (uint32_t)((p & 1) * 8);
-    short4v lo = lds_read_tr16(tile + tile_off<false>(klo, m0 >> 3) + sub);
-    short4v hi = lds_read_tr16(tile + tile_off<false>(klo + 4, m0 >> 3) + sub);
-    return join_tr(lo, hi);
-  }
+// Transposed LDS read issued as inline asm: with the builtin, hipcc cannot prove the read does not alias the LDS-DMA writes
+// still in flight and drains them (`s_waitcnt vmcnt(0)`) in front of every fragment group, which serialises the
+// pipeline.  The asm form is invisible to that analysis; its completion is covered by tr_wait() below.
+__device__ __forceinline__ short4v tr_read_asm(uint32_t lds_addr) {
+  short4v r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_addr));
+  return r;
+}
+// s_waitcnt lgkmcnt(0) that data-depends on every register the asm reads above wrote (guide 5.7, form ii): nothing that
+// consumes them can be scheduled above the wait.
+__device__ __forceinline__ void tr_wait(short4v (&p)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7])
+               :
+               : "memory");
+}
+
+// k-major fragment: one ds_read_b128 (compiler-tracked)
+__device__ __forceinline__ bf16x8 read_frag_km(const char* tile, int rbase, int s, int lane) {
+  const int r = rbase + (lane & 31);
+  return *(const bf16x8*)(tile + tile_off<true>(r, 2 * s + (lane >> 5)));
+}
+// m/n-major fragment, raw halves (join after tr_wait)
+__device__ __forceinline__ void read_frag_tr(uint32_t tile_lds, int rbase, int s, int lane, short4v& lo, short4v& hi) {
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3, h = g >> 1;
+  const int m0 = rbase + 16 * (g & 1) + 4 * p;
+  const int klo = 16 * s + 8 * h + q;
+  const uint32_t sub = (uint32_t)((p & 1) * 8);
+  lo = tr_read_asm(tile_lds + tile_off<false>(klo, m0 >> 3) + sub);
+  hi = tr_read_asm(tile_lds + tile_off<false>(klo + 4, m0 >> 3) + sub);
 }
 
 // Source address (element offset from the operand base, at k-tile 0) of the 16 bytes lane `lane` contributes to 1 KiB
@@ -116,6 +132,11 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(Args g) {
 #pragma unroll
     for (int j = 0; j < PPW; ++j) G2_GLDS(src[j] + (long)t * kstep[j], sb + dst[j]);
   };
+  auto issue_part = [&](int t, int j0) {           // two of the six pieces: spread between the MFMA groups of a K-step
+    const uint32_t sb = lds0 + (uint32_t)((t % NS) * STAGE);
+    G2_GLDS(src[j0] + (long)t * kstep[j0], sb + dst[j0]);
+    G2_GLDS(src[j0 + 1] + (long)t * kstep[j0 + 1], sb + dst[j0 + 1]);
+  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -133,16 +154,38 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(Args g) {
       if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                // also: every wave is done reading stage (t+2) % NS (tile t-1)
-      if (t + 2 < nk) issue(t + 2);
+      const bool pre = t + 2 < nk;
       const char* sa = smem + (t % NS) * STAGE + (wm >> 1) * SUB;
       const char* sb = smem + (t % NS) * STAGE + 2 * SUB;
 #pragma unroll
       for (int s = 0; s < BK / 16; ++s) {
         bf16x8 fa[2], fb[2];
-        fa[0] = read_frag<AKM>(sa, (wm & 1) * 64, s, lane);
-        fa[1] = read_frag<AKM>(sa, (wm & 1) * 64 + 32, s, lane);
-        fb[0] = read_frag<BKM>(sb, wn * 64, s, lane);
-        fb[1] = read_frag<BKM>(sb, wn * 64 + 32, s, lane);
+        short4v raw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) raw[i] = short4v{0, 0, 0, 0};
+        const uint32_t sa_l = lds0 + (uint32_t)(sa - smem), sb_l = lds0 + (uint32_t)(sb - smem);
+        if (AKM) {
+          fa[0] = read_frag_km(sa, (wm & 1) * 64, s, lane);
+          fa[1] = read_frag_km(sa, (wm & 1) * 64 + 32, s, lane);
+        } else {
+          read_frag_tr(sa_l, (wm & 1) * 64, s, lane, raw[0], raw[1]);
+          read_frag_tr(sa_l, (wm & 1) * 64 + 32, s, lane, raw[2], raw[3]);
+        }
+        if (BKM) {
+          fb[0] = read_frag_km(sb, wn * 64, s, lane);
+          fb[1] = read_frag_km(sb, wn * 64 + 32, s, lane);
+        } else {
+          read_frag_tr(sb_l, wn * 64, s, lane, raw[4], raw[5]);
+          read_frag_tr(sb_l, wn * 64 + 32, s, lane, raw[6], raw[7]);
+        }
+        if (!AKM || !BKM) {
+          tr_wait(raw);
+          if (!AKM) { fa[0] = join_tr(raw[0], raw[1]); fa[1] = join_tr(raw[2], raw[3]); }
+          if (!BKM) { fb[0] = join_tr(raw[4], raw[5]); fb[1] = join_tr(raw[6], raw[7]); }
+        }
+        // tile t+2's LDS-DMA is issued two pieces at a time BETWEEN the MFMA groups (not all six right after the
+        // barrier, where every wave would sit in ~60-cycle issue slots with the matrix pipe idle)
+        if (pre && s < 3) issue_part(t + 2, 2 * s);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll

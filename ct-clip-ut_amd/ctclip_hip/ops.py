@@ -89,8 +89,13 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_dtype=BF1
 
 
 def _splits_for(m_out: int, n_out: int, k: int) -> int:
-    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    """split-K factor of a weight-gradient GEMM (small m_out x n_out, contraction over all tokens): about two waves of
+    256x128 workgroups on the 256 CUs (the pipelined kernel runs one workgroup per CU), at least 8 k-tiles per split."""
     nk = (k + 63) // 64
+    if k % 64 == 0:
+        tiles = ((m_out + 255) // 256) * ((n_out + 127) // 128)
+        return max(1, min(nk // 8 if nk >= 8 else 1, (512 + tiles - 1) // tiles))
+    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
     return max(1, min(nk, (1024 + tiles - 1) // tiles))
 
 
@@ -111,9 +116,18 @@ def colsum(x2d, out=None):
     return out
 
 
-def dgrad(dy16, w16, tokens, n_feat, k_feat, *, out_dtype=F32, resid=None):
-    """dx[tokens,k_feat] = dy[tokens,n_feat] W[n_feat,k_feat]."""
+def dgrad(dy16, w16, tokens, n_feat, k_feat, *, out_dtype=F32, resid=None, wT16=None):
+    """dx[tokens,k_feat] = dy[tokens,n_feat] W[n_feat,k_feat].
+
+    With wT16 = W^T stored [k_feat, n_feat] (a transposed bf16 shadow of the small weight) the product is k-major x
+    k-major, i.e. exactly the forward layout, and runs on the pipelined LDS-DMA kernel."""
+    if wT16 is not None:
+        return gemm(dy16, wT16, tokens, k_feat, n_feat, a_kmajor=True, b_kmajor=True, out_dtype=out_dtype, resid=resid)
     return gemm(dy16, w16, tokens, k_feat, n_feat, a_kmajor=True, b_kmajor=False, out_dtype=out_dtype, resid=resid)
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
 
 
 def layernorm(x2d, gamma, beta, eps, want16=True, want32=False):
@@ -288,7 +302,7 @@ class AttentionFn(Function):
             bias_dense = None
         dy2 = _c(dy).reshape(M, dim)
         dyb = _get16(dy)
-        do = dgrad(dyb, sh["wout"], M, dim, inner, out_dtype=BF16)
+        do = dgrad(dyb, sh["wout"], M, dim, inner, out_dtype=BF16, wT16=sh.get("woutT"))
         dqh = torch.empty(M, inner, dtype=BF16, device=dev)
         dkh = torch.empty(M, inner, dtype=BF16, device=dev)
         dkv = torch.empty(M, 2 * inner, dtype=BF16, device=dev)
@@ -323,9 +337,9 @@ class AttentionFn(Function):
             wgrad(dyb, o, dim, inner, M, out=gwo)
             hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, inner, inner, float(scale))
             hip.headnorm_bwd(dkh, kv, kinv, sh["k_scale"], dkv, gks, M, heads, dp, inner, 2 * inner, 2 * inner, 1.0)
-            dn1 = dgrad(dq, sh["wq"], M, inner, dim)
+            dn1 = dgrad(dq, sh["wq"], M, inner, dim, wT16=sh.get("wqT"))
             wgrad(dq, n1, inner, dim, M, out=gwq)
-            dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None)
+            dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None, wT16=sh.get("wkvT"))
             wgrad(dkv, xb, 2 * inner, dim, M, out=gwkv)
             dx16 = torch.empty(M, dim, dtype=BF16, device=dev)
             hip.layernorm_bwd(dn1, x2, gamma, mean, rstd, dxkv, dx, dx16, gg, None, M, dim)
@@ -336,9 +350,9 @@ class AttentionFn(Function):
         dks = torch.zeros(dp, dtype=F32, device=dev)
         hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, dqs, M, heads, dp, inner, inner, inner, float(scale))
         hip.headnorm_bwd(dkh, kv, kinv, sh["k_scale"], dkv, dks, M, heads, dp, inner, 2 * inner, 2 * inner, 1.0)
-        dn1 = dgrad(dq, sh["wq"], M, inner, dim)
+        dn1 = dgrad(dq, sh["wq"], M, inner, dim, wT16=sh.get("wqT"))
         dwq = wgrad(dq, n1, inner, dim, M)
-        dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None)
+        dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None, wT16=sh.get("wkvT"))
         dwkv = wgrad(dkv, xb, 2 * inner, dim, M)
         dgamma = torch.zeros_like(gamma)
         hip.layernorm_bwd(dn1, x2, gamma, mean, rstd, dxkv, dx, None, dgamma, None, M, dim)
@@ -384,11 +398,11 @@ class FeedForwardFn(Function):
         gw2, d2 = grad_slot(p_w2)
         glw, d3 = grad_slot(p_lw)
         glb, d4 = grad_slot(p_lb)
-        dg = dgrad(dyb, sh["w2"], M, dim, Ip, out_dtype=BF16)
+        dg = dgrad(dyb, sh["w2"], M, dim, Ip, out_dtype=BF16, wT16=sh.get("w2T"))
         wgrad(dyb, g, dim, I, M, out=gw2)                          # g's zero pad columns I..Ip-1 are simply not produced
         dh = torch.empty_like(h)
         hip.geglu_bwd(dg, h, dh, M, Ip, Ip, 2 * Ip)
-        dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim)
+        dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim, wT16=sh.get("w1T"))
         wgrad(dh, n2, I, dim, M, out=gw1[:I])                      # value half  (rows 0..I-1 of the reference weight)
         wgrad(dh[:, Ip:], n2, I, dim, M, out=gw1[I:])              # gate half   (rows I..2I-1)
         dx = torch.empty(M, dim, dtype=F32, device=dy.device)
@@ -486,7 +500,7 @@ class PatchEmbedFn(Function):
         colsum(dz, out=db)
         dw, k4 = grad_slot(p_w)
         wgrad(dzb, A, dim, F_, M, out=dw)
-        dA = dgrad(dzb, sh["w"], M, dim, ldA, out_dtype=BF16)
+        dA = dgrad(dzb, sh["w"], M, dim, ldA, out_dtype=BF16, wT16=sh.get("wT"))
         d1w, k5 = grad_slot(p_l1w)
         d1b, k6 = grad_slot(p_l1b)
         hip.patch_ln_bwd(vol, int(vol.dtype == BF16), dA, ldA, mean1, rstd1, d1w, d1b, B, C, Dz, Hy, Wx, tpatch, patch)

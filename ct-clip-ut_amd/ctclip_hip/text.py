@@ -109,19 +109,19 @@ class BertLayerFn(Function):
         do2b = torch.empty(M, Hd, dtype=BF16, device=dev)
         hip.layernorm_bwd(ops._c(dy), o2, l2w, mean2, rstd2, None, do2, do2b, g[14], g[15], M, Hd)
         ops.colsum(do2, out=g[13])
-        dm = ops.dgrad(do2b, sh["wo"], M, Hd, I, out_dtype=BF16)
+        dm = ops.dgrad(do2b, sh["wo"], M, Hd, I, out_dtype=BF16, wT16=sh.get("woT"))
         ops.wgrad(do2b, m, Hd, I, M, out=g[12])
         dh_ = torch.empty_like(hpre)
         hip.gelu_bwd(dm, hpre, dh_, hpre.numel())
         ops.colsum(dh_, out=g[11])
-        dx1 = ops.dgrad(dh_, sh["wi"], M, I, Hd, resid=do2)
+        dx1 = ops.dgrad(dh_, sh["wi"], M, I, Hd, resid=do2, wT16=sh.get("wiT"))
         ops.wgrad(dh_, x1_16, I, Hd, M, out=g[10])
         # attention-output LayerNorm
         da = torch.empty(M, Hd, dtype=F32, device=dev)
         dab = torch.empty(M, Hd, dtype=BF16, device=dev)
         hip.layernorm_bwd(dx1, a, l1w, mean1, rstd1, None, da, dab, g[8], g[9], M, Hd)
         ops.colsum(da, out=g[7])
-        do = ops.dgrad(dab, sh["wao"], M, Hd, inner, out_dtype=BF16)
+        do = ops.dgrad(dab, sh["wao"], M, Hd, inner, out_dtype=BF16, wT16=sh.get("waoT"))
         ops.wgrad(dab, o, Hd, inner, M, out=g[6])
         dqkv = torch.empty(M, 3 * inner, dtype=BF16, device=dev)
         delta = torch.empty(B, heads, L, dtype=F32, device=dev)
@@ -133,7 +133,7 @@ class BertLayerFn(Function):
             part = dqkv[:, j * inner:(j + 1) * inner]
             ops.colsum(part, out=g[2 * j + 1])
             ops.wgrad(part, xb, inner, Hd, M, out=g[2 * j])
-        dx = ops.dgrad(dqkv, sh["wqkv"], M, 3 * inner, Hd, resid=da)
+        dx = ops.dgrad(dqkv, sh["wqkv"], M, 3 * inner, Hd, resid=da, wT16=sh.get("wqkvT"))
         return (dx, None, None, None) + tuple(ops._ret(b, d) for b, d in G)
 
     @staticmethod
@@ -154,12 +154,12 @@ class BertLayerFn(Function):
         dl2w, dl2b = z(Hd), z(Hd)
         hip.layernorm_bwd(ops._c(dy), o2, l2w, mean2, rstd2, None, do2, do2b, dl2w, dl2b, M, Hd)
         dbo = ops.colsum(do2)
-        dm = ops.dgrad(do2b, sh["wo"], M, Hd, I, out_dtype=BF16)
+        dm = ops.dgrad(do2b, sh["wo"], M, Hd, I, out_dtype=BF16, wT16=sh.get("woT"))
         dwo = ops.wgrad(do2b, m, Hd, I, M)
         dh_ = torch.empty_like(hpre)
         hip.gelu_bwd(dm, hpre, dh_, hpre.numel())
         dbi = ops.colsum(dh_)
-        dx1 = ops.dgrad(dh_, sh["wi"], M, I, Hd, resid=do2)
+        dx1 = ops.dgrad(dh_, sh["wi"], M, I, Hd, resid=do2, wT16=sh.get("wiT"))
         dwi = ops.wgrad(dh_, x1_16, I, Hd, M)
         # attention-output LayerNorm
         da = torch.empty(M, Hd, dtype=F32, device=dev)
@@ -167,7 +167,7 @@ class BertLayerFn(Function):
         dl1w, dl1b = z(Hd), z(Hd)
         hip.layernorm_bwd(dx1, a, l1w, mean1, rstd1, None, da, dab, dl1w, dl1b, M, Hd)
         dbao = ops.colsum(da)
-        do = ops.dgrad(dab, sh["wao"], M, Hd, inner, out_dtype=BF16)
+        do = ops.dgrad(dab, sh["wao"], M, Hd, inner, out_dtype=BF16, wT16=sh.get("waoT"))
         dwao = ops.wgrad(dab, o, Hd, inner, M)
         dqkv = torch.empty(M, 3 * inner, dtype=BF16, device=dev)
         delta = torch.empty(B, heads, L, dtype=F32, device=dev)
@@ -176,7 +176,7 @@ class BertLayerFn(Function):
                      3 * inner, 3 * inner, 3 * inner, inner, inner, 3 * inner, 3 * inner, 3 * inner,
                      1.0 / math.sqrt(dh))
         dbqkv = ops.colsum(dqkv)
-        dx = ops.dgrad(dqkv, sh["wqkv"], M, 3 * inner, Hd, resid=da)
+        dx = ops.dgrad(dqkv, sh["wqkv"], M, 3 * inner, Hd, resid=da, wT16=sh.get("wqkvT"))
         dwqkv = ops.wgrad(dqkv, xb, 3 * inner, Hd, M)
         un = lambda w: ops.unpad_head_rows(w, heads, dh, dp)
         unb = lambda b_: ops.unpad_head_rows(b_[:, None], heads, dh, dp)[:, 0]
@@ -202,12 +202,15 @@ def _layer_shadows(layer, heads, dh, dp):
     def build():
         pad = lambda w: ops.pad_head_rows(w, heads, dh, dp)
         padb = lambda b: ops.pad_head_rows(b[:, None], heads, dh, dp)[:, 0]
-        return {
+        d = {
             "wqkv": torch.cat((pad(p[0]), pad(p[2]), pad(p[4])), 0).to(BF16).contiguous(),
             "bqkv": torch.cat((padb(p[1]), padb(p[3]), padb(p[5]))).to(F32).contiguous(),
             "wao": pad(p[6].t()).t().to(BF16).contiguous(),
             "wi": p[10].to(BF16).contiguous(), "wo": p[12].to(BF16).contiguous(), "inter": p[10].shape[0],
         }
+        d.update(wqkvT=d["wqkv"].t().contiguous(), waoT=d["wao"].t().contiguous(), wiT=d["wi"].t().contiguous(),
+                 woT=d["wo"].t().contiguous())
+        return d
 
     return cache.get("bert", p, build)
 

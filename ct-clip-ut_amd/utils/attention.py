@@ -73,7 +73,7 @@ class FeedForward(nn.Sequential):
 
     def _shadows(self):
         w1, w2 = self[1].weight, self[4].weight
-        I, Ip = self.inner, ops.pad8(self.inner)
+        I, Ip = self.inner, ops.pad64(self.inner)      # 1365 -> 1408: every K of the MLP is a whole number of 64-wide k-tiles
 
         def build():
             w1p = torch.zeros(2 * Ip, self.dim, dtype=BF16, device=w1.device)
@@ -81,7 +81,7 @@ class FeedForward(nn.Sequential):
             w1p[Ip:Ip + I] = w1[I:]
             w2p = torch.zeros(self.dim, Ip, dtype=BF16, device=w2.device)
             w2p[:, :I] = w2
-            return {"w1": w1p, "w2": w2p, "inner": I, "inner_p": Ip}
+            return {"w1": w1p, "w2": w2p, "w1T": w1p.t().contiguous(), "w2T": w2p.t().contiguous(), "inner": I, "inner_p": Ip}
 
         return self._shadow.get("ff", (w1, w2), build)
 
@@ -165,12 +165,15 @@ class Attention(nn.Module):
             k_w, v_w = wkv[:inner], wkv[inner:]
             pad = lambda w: ops.pad_head_rows(w, H, dh, dp)
             scale_p = lambda s: torch.cat((s.detach().to(F32), s.new_zeros(dp - dh))) if dp != dh else s.detach().to(F32).clone()
-            return {
+            d = {
                 "wq": pad(wq).to(BF16).contiguous(),
                 "wkv": torch.cat((pad(k_w), pad(v_w)), 0).to(BF16).contiguous(),
                 "wout": pad(wo.t()).t().to(BF16).contiguous(),
                 "q_scale": scale_p(qs), "k_scale": scale_p(ks),
             }
+            # transposed copies of the (small) weights: dgrad then has the forward's k-major x k-major layout
+            d.update(wqT=d["wq"].t().contiguous(), wkvT=d["wkv"].t().contiguous(), woutT=d["wout"].t().contiguous())
+            return d
 
         return self._shadow.get("attn", (wq, wkv, wo, qs, ks), build)
 

@@ -70,9 +70,11 @@ class CTViT(nn.Module):
         if not image.is_cuda:
             raise RuntimeError("CTViT: MI355X HIP path only (no CPU fallback); move the volume to cuda")
         _, ln1, lin, ln2 = self.to_patch_emb
-        sh = self._shadow.get("patch", (lin.weight,),
-                              lambda: {"w": torch.nn.functional.pad(lin.weight, (0, ops.pad8(lin.weight.shape[1]) -
-                                                                                 lin.weight.shape[1])).to(BF16).contiguous()})
+        def build():
+            w = torch.nn.functional.pad(lin.weight, (0, ops.pad8(lin.weight.shape[1]) - lin.weight.shape[1])).to(BF16).contiguous()
+            return {"w": w, "wT": w.t().contiguous()}
+
+        sh = self._shadow.get("patch", (lin.weight,), build)
         if image.dtype not in (F32, BF16):
             image = image.to(F32)
         return ops.PatchEmbedFn.apply(image, ln1.weight, ln1.bias, lin.weight, lin.bias, ln2.weight, ln2.bias, sh,
