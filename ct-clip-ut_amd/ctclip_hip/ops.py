@@ -164,6 +164,16 @@ def _ret(buf, direct):
     return None if direct else buf
 
 
+# Optional callback(param) fired by a backward as soon as a parameter's gradient has been fully ISSUED into its arena slot.
+# GradSync installs it to start that slice's RCCL all-reduce early (overlap with the rest of backward).
+grad_ready_hook = None
+
+
+def _grad_ready(p, direct):
+    if direct and grad_ready_hook is not None:
+        grad_ready_hook(p)
+
+
 def _tag16(t32, t16):
     """Attach the bf16 copy a kernel produced for free to the f32 gradient it mirrors.  The next Function.backward picks
     it up with _get16 instead of launching a cast kernel; the pointer check makes a stale or re-wrapped tensor harmless."""
@@ -619,6 +629,7 @@ class VisualLatentFn(Function):
             # accumulate the (dim_latent x dim_image) weight gradient straight into the arena-backed .grad
             gemm(dyb, a16, L, Fdim, B, a_kmajor=False, b_kmajor=False, out=w.grad, accumulate=True)
             dw = None
+            _grad_ready(w, True)            # 53 % of all gradient bytes, ready at the very start of backward
         else:
             dw = wgrad(dyb, a16, L, Fdim, B)
         return dtok, dw, None

@@ -135,9 +135,33 @@ class GradSync:
     With 7 xGMI peers a few large collectives keep every link busy; bucket_mb sizes the slices so the first ones
     (issued as soon as backward ends) overlap with the rest of the host-side step."""
 
-    def __init__(self, optimizer: HipAdam, bucket_mb: int = 128, group=None):
+    def __init__(self, optimizer: HipAdam, bucket_mb: int = 128, group=None, overlap: bool = True):
         self.opt, self.group = optimizer, group
         self.bucket_elems = bucket_mb * (1 << 20) // 4
+        self._early = []            # (arena index, start, stop, work handle or (handle, chunk)) launched during backward
+        if overlap:
+            from . import ops
+            ops.grad_ready_hook = self.early_reduce
+
+    def _launch(self, chunk):
+        w = self.world()
+        if chunk.is_cuda and dist.get_backend(self.group) == "nccl":
+            return dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        return (dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk)
+
+    def early_reduce(self, param):
+        """Called from a backward once `param`'s gradient kernels have been issued: start its all-reduce now, on RCCL's
+        stream (which first waits for the work already queued on the compute stream), and remember the slice."""
+        if self.world() == 1 or not self.opt._built:
+            return
+        for ai, a in enumerate(self.opt._arenas):
+            if a is None:
+                continue
+            for p, o in zip(a["params"], a["offs"]):
+                if p is param:
+                    start, stop = o, o + p.numel()
+                    self._early.append((ai, start, stop, self._launch(a["g"][start:stop])))
+                    return
 
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
@@ -146,15 +170,26 @@ class GradSync:
         w = self.world()
         if w == 1:
             return
-        handles = []
-        for g in self.opt.flat_grads():
+        handles = [e[3] for e in self._early]
+        arenas = [a for a in getattr(self.opt, "_arenas", []) if a is not None] if hasattr(self.opt, "_arenas") else None
+        grads = self.opt.flat_grads()
+        for gi, g in enumerate(grads):
             n = g.numel()
-            for s in range(0, n, self.bucket_elems):
-                chunk = g[s:min(n, s + self.bucket_elems)]
-                if g.is_cuda and dist.get_backend(self.group) == "nccl":
-                    handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-                else:   # gloo (CPU tests) has no AVG
-                    handles.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
+            # slices not already in flight: the gaps around the early-reduced ranges of this arena
+            done = sorted((s0, s1) for (ai, s0, s1, _) in self._early
+                          if arenas is not None and arenas[gi] is self.opt._arenas[ai])
+            pos = 0
+            gaps = []
+            for s0, s1 in done:
+                if s0 > pos:
+                    gaps.append((pos, s0))
+                pos = max(pos, s1)
+            if pos < n:
+                gaps.append((pos, n))
+            for g0, g1 in gaps:
+                for s in range(g0, g1, self.bucket_elems):
+                    handles.append(self._launch(g[s:min(g1, s + self.bucket_elems)]))
+        self._early = []
         for h in handles:
             if isinstance(h, tuple):
                 h[0].wait()

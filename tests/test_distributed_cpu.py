@@ -90,6 +90,40 @@ def test_gradsync_bucketed_average():
     _run(_bucketed_allreduce)
 
 
+def _early_reduce_then_rest(rank):
+    """A parameter whose gradient is announced during backward is all-reduced early; all_reduce_grads() then covers exactly
+    the remaining gaps of the arena, so every element is averaged exactly once."""
+    from ctclip_hip.optim import GradSync
+
+    class Arena:
+        _built = True
+
+        def __init__(self):
+            torch.manual_seed(100 + rank)
+            self.params = [torch.nn.Parameter(torch.zeros(n)) for n in (40, 300, 17)]
+            self.offs = [0, 40, 340]
+            self.g = torch.randn(360)
+            self._arenas = [None, dict(g=self.g, params=self.params, offs=self.offs)]
+
+        def flat_grads(self):
+            return [self.g]
+
+    ar = Arena()
+    everyone = [torch.zeros(360) for _ in range(WORLD)]
+    dist.all_gather(everyone, ar.g.clone())
+    sync = GradSync(ar, overlap=False)
+    sync.bucket_elems = 64
+    sync.early_reduce(ar.params[1])                                            # the middle slice goes first
+    assert len(sync._early) == 1 and sync._early[0][1:3] == (40, 340)
+    sync.all_reduce_grads()
+    torch.testing.assert_close(ar.g, sum(everyone) / WORLD)
+    assert sync._early == []
+
+
+def test_gradsync_early_slice_plus_gaps_average_once():
+    _run(_early_reduce_then_rest)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def _global_contrastive_grad_scaling(rank):
     """Two ranks with B pairs each + all-gather == one process with the 2B batch, up to the reference's scaling quirk."""
