@@ -214,7 +214,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "text_len": args.text_len,
                        "negatives": "local" if args.local_negatives or world == 1 else "global (all-gather)",
                        "parallelism": f"dp{world}", "peak_hbm_gib": round(peak_mem, 1), "final_loss": float(loss)},
-            "roofline": {"kernel": "gemm_bf16_kernel (all operand layouts)", "bound": "mfma", "achieved": gemm_tflops,
+            "roofline": {"kernel": "ctclip_gemm_bf16 family (gemm2_kernel 256x128x64 LDS-DMA ring; gemm_bf16_kernel 128x128 for small grids)", "bound": "mfma", "achieved": gemm_tflops,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_BF16_TFLOPS,
                          "traffic": None, "launches_per_step": timing["launches"] / args.steps,
                          "gemm_ms_per_step": timing["total_ms"] / args.steps},

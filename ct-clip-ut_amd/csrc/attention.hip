@@ -23,103 +23,9 @@
 //     log-sum-exp.  d(bias) is reduced on chip into a [heads][R] relative-position table through
 //     LDS atomics (the CT-ViT bias has only (2h-1)(2w-1) distinct values per head), or, for
 //     arbitrary biases, added to a dense [heads,n,n] buffer with global atomics.
-#include "common.h"
+#include "attn_common.h"
 
 namespace {
-
-struct AttnArgs {
-  const bf16_t* q; const bf16_t* k; const bf16_t* v;
-  bf16_t* o;                 // fwd out
-  float* lse;                // [nseq, H, n]
-  const float* bias;         // [H, n, n] or null
-  const float* mask;         // [nseq, n] additive or null
-  const bf16_t* dO;          // bwd
-  const bf16_t* oin;         // bwd: forward output (for delta)
-  float* delta;              // [nseq, H, n]
-  bf16_t* dq; bf16_t* dk; bf16_t* dv;
-  float* dbias_dense;        // [H, n, n] or null
-  const uint16_t* relidx;    // [n, n] or null
-  float* dbias_table;        // [H, R] or null
-  int table_size;            // R
-  int grid_h, grid_w;        // >0: relidx[i][j] = (yi-yj+h-1)*(2w-1) + (xi-xj+w-1) computed on the fly (i = y*w + x)
-  long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
-  int nseq, n, n_pad, heads;
-  float scale;
-};
-
-template <int D>
-__device__ __forceinline__ uint32_t img_off(int row, int chunk) {
-  if (D == 32) return (uint32_t)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
-  return (uint32_t)(row * 128 + ((chunk ^ (((row >> 2) & 3) | (((row >> 1) & 1) << 2))) << 4));
-}
-
-// stage rows [0,n) of a [*, ld] matrix (columns head*D..) into a swizzled LDS image; rows n..n_pad-1 = 0
-template <int D>
-__device__ __forceinline__ void load_image(char* img, const bf16_t* __restrict__ base, long ld, int n, int n_pad,
-                                           int tid, int nthreads) {
-  constexpr int CH = D / 8;
-  for (int id = tid; id < n_pad * CH; id += nthreads) {
-    const int r = id / CH, c = id % CH;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (r < n) v = *(const uint4*)(base + (long)r * ld + c * 8);
-    *(uint4*)(img + img_off<D>(r, c)) = v;
-  }
-}
-
-// A/B fragment for MFMA 32x32x16: element j = M[row0 + (lane&31)][16*s + 8*(lane>>5) + j]
-template <int D>
-__device__ __forceinline__ bf16x8 row_frag(const char* img, int row0, int s, int lane) {
-  return *(const bf16x8*)(img + img_off<D>(row0 + (lane & 31), 2 * s + (lane >> 5)));
-}
-
-// transposed fragment: element j = M[row0 + 16*s + 8*(j>>2) + 4*(lane>>5) + (j&3)][32*dt + (lane&31)]
-// (the k-order an f32 32x32 accumulator has when it is re-used as the other operand)
-template <int D>
-__device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int s, int dt, int lane) {
-  const int g = lane >> 4, i16 = lane & 15, qq = i16 >> 2, p = i16 & 3, h = g >> 1;
-  const int col = 32 * dt + 16 * (g & 1) + 4 * p;
-  const int rlo = row0 + 16 * s + 4 * h + qq;
-  const uint32_t sub = (uint32_t)((p & 1) * 8);
-  short4v lo = lds_read_tr16(img + img_off<D>(rlo, col >> 3) + sub);
-  short4v hi = lds_read_tr16(img + img_off<D>(rlo + 8, col >> 3) + sub);
-  return join_tr(lo, hi);
-}
-
-// fragment straight from global memory: element j = M[row][16*s + 8*(lane>>5) + j]
-__device__ __forceinline__ bf16x8 gfrag(const bf16_t* __restrict__ rowptr, int s, int lane, bool valid) {
-  short8v z = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (valid) z = *(const short8v*)(rowptr + 16 * s + 8 * (lane >> 5));
-  return as_bf16x8(z);
-}
-
-// registers 8s..8s+7 of an accumulator -> bf16 fragment of k-step s
-__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
-  bf16x8 r;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (__bf16)a[8 * s + j];
-  return r;
-}
-
-__device__ __forceinline__ void zero_acc(f32x16& a) {
-#pragma unroll
-  for (int i = 0; i < 16; ++i) a[i] = 0.f;
-}
-
-// store one wave's [D x 32] transposed accumulator tile as rows of a [*, ld] bf16 matrix:
-// lane (r, h) owns row `row`, columns 32*dt + 8*g4 + 4*h + (0..3)
-template <int D>
-__device__ __forceinline__ void store_rows(bf16_t* __restrict__ rowptr, const f32x16 (&acc)[D / 32], float mul, int lane) {
-  const int h = lane >> 5;
-#pragma unroll
-  for (int dt = 0; dt < D / 32; ++dt)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      uint2 p;
-      p.x = pack_bf16x2(acc[dt][4 * g4 + 0] * mul, acc[dt][4 * g4 + 1] * mul);
-      p.y = pack_bf16x2(acc[dt][4 * g4 + 2] * mul, acc[dt][4 * g4 + 3] * mul);
-      *(uint2*)(rowptr + 32 * dt + 8 * g4 + 4 * h) = p;
-    }
-}
 
 // additive terms of one 32x32 score tile in "row of accumulator = key, lane = query" orientation:
 // add[reg] = bias[head][q][key] + mask[key]  (0 where absent).  Issued one tile AHEAD of its use so the L2
@@ -544,6 +450,10 @@ int ctclip_attn_fwd(const void* q, const void* k, const void* v, void* o, float*
   a.bias = bias; a.mask = mask; a.nseq = nseq; a.n = n; a.n_pad = (n + 31) / 32 * 32; a.heads = heads;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
   if (int e = check(a, dhead)) return e;
+  {
+    const int e = ctclip_attn_sp_fwd(a, dhead, (hipStream_t)stream);   // long rows: sequence-persistent kernels
+    if (e >= 0) return e;
+  }
   const int nw = waves_for(n, dhead);
   dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
   const size_t lds = (size_t)a.n_pad * dhead * 2;
@@ -575,6 +485,10 @@ int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, 
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.lddo = lddo; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.scale = scale;
   if (int e = check(a, dhead)) return e;
+  {
+    const int e = ctclip_attn_sp_bwd(a, dhead, (hipStream_t)stream);
+    if (e >= 0) return e;
+  }
   // both backward passes use 6-wave workgroups: two of them fit per CU at their register budgets (12 resident waves)
   const int nw = waves_for(n, dhead, 6);
   dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);

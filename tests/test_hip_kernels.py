@@ -223,9 +223,15 @@ def attn_ref(q, k, v, bias, mask, scale):
     (2, 40, 2, 32, True, False),       # ragged: n not a multiple of 32
     (2, 6, 4, 32, True, True),         # n % 4 != 0
     (1, 512, 2, 64, False, True),      # BERT L=512 (128 KiB of LDS)
+    (7, 320, 3, 32, True, False),      # sequence-persistent kernels, 10 tiles over 8 waves (2 + 1 per wave)
+    (5, 256, 2, 32, False, False),     # sequence-persistent kernels without a bias
 ])
-def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask):
+def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask, monkeypatch):
     scale = 1.0 if D == 32 else 1.0 / math.sqrt(D)
+    if n == 320:
+        scale = 0.75                   # exercises the bias / scale folding of the persistent kernels
+    if D == 32 and n % 32 == 0 and nseq > 2:
+        monkeypatch.setenv("CTCLIP_ATTN_SP_CHUNK", "3")   # several sequences per workgroup + a ragged last chunk
     ld = H * D
     q, k, v = (rnd(nseq * n, ld, seed=s) for s in (20, 21, 22))
     if D == 32:   # what ctclip_headnorm_fwd feeds the kernel: unit rows per head, q carries the fixed scale 8

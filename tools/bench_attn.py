@@ -30,4 +30,9 @@ for name, nseq, n, H, D, gh, gw in (("spatial", 24 * B, 576, 8, 32, 24, 24), ("t
     t = timeit(fwd); print(f"{name:9s} fwd            {t:9.1f} us  {flops / t / 1e6:7.1f} TFLOP/s")
     t = timeit(lambda: bwd(False)); print(f"{name:9s} bwd (no dbias) {t:9.1f} us  {2.5 * flops / t / 1e6:7.1f} TFLOP/s")
     if gh:
+        keep = bias
+        bias = None
+        t = timeit(fwd); print(f"{name:9s} fwd  (bias=None)      {t:9.1f} us")
+        t = timeit(lambda: bwd(False)); print(f"{name:9s} bwd  (bias=None)      {t:9.1f} us")
+        bias = keep
         t = timeit(lambda: bwd(True)); print(f"{name:9s} bwd (+table)   {t:9.1f} us  {2.5 * flops / t / 1e6:7.1f} TFLOP/s")
