@@ -9,6 +9,7 @@
 // Weights are passed tap-major: w27[tap][d], tap = (kt*3 + kh)*3 + kw  (a transposed copy of
 // dsconv.weight[d,1,3,3,3]) so that a wave reads one coalesced row per tap.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -174,6 +175,294 @@ __global__ __launch_bounds__(256) void peg_bwd_weight_kernel(const float* __rest
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Plane-tiled sweep (the production path for h*w*4/PL_P*... <= 640 threads, i.e. the 24x24 CT-ViT grid).
+// A workgroup owns (batch item, 16-channel slice) and sweeps t.  Each (t) plane of that slice is loaded ONCE from global
+// memory into a zero-bordered LDS image [(H+2)][(Wp+2)][4 float4] (double-buffered, the next plane is in flight while
+// this one is consumed); the 3x3 (h,w) neighbourhood then comes from LDS, so global traffic is exactly one read of x and
+// one write of y (+ y16) -- peg_sweep_kernel above pulls every element 3.75 times through L2 and re-reads x for the
+// residual.  One thread = 4 channels x PL_P consecutive w positions, three rotating accumulator sets as above.
+constexpr int PL_P = 6;            // outputs per thread along w (24 = 4 strips)
+constexpr int PL_CG = 4;            // float4 channel groups per workgroup (16 channels)
+constexpr int PL_MAXT = 512;        // 8 waves -> 2 per SIMD -> 256 registers per thread
+
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool FWD>
+__global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restrict__ x, const float* __restrict__ w27,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            bf16_t* __restrict__ y16, Grid5 g, int residual, int strips) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 pl_smem[];
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  const int nslices = g.d4 / PL_CG;
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = blk % nslices;
+  const long b = blk / nslices;
+  const int cg = tid & (PL_CG - 1), sid = tid >> 2;
+  const int h_ = sid / strips, w0 = (sid % strips) * PL_P;
+  const bool active = h_ < g.H;
+  const int pitch = strips * PL_P + 2;                       // padded row length (positions)
+  const int plane_f4 = (g.H + 2) * pitch * PL_CG;
+  f32x4* wl = pl_smem;                                      // [27][PL_CG]
+  f32x4* plane = pl_smem + 27 * PL_CG;                      // [2][(H+2)][pitch][PL_CG]
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 27 * PL_CG; i += nthreads) wl[i] = ((const f32x4*)w27)[(i / PL_CG) * g.d4 + slice * PL_CG + (i % PL_CG)];
+  for (int i = tid; i < 2 * plane_f4; i += nthreads) plane[i] = zero;
+  const int c = slice * PL_CG + cg;
+  const f32x4* xv = (const f32x4*)x;
+  f32x4 bv = zero;
+  if (FWD && active) bv = ((const f32x4*)bias)[c];
+  f32x4 acc[3][PL_P];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < PL_P; ++i) acc[a][i] = zero;
+
+  f32x4 nx[PL_P];
+  auto load_plane = [&](int t) {
+    const long row = ((b * g.T + t) * g.H + h_) * g.W;
+#pragma unroll
+    for (int i = 0; i < PL_P; ++i) nx[i] = (active && w0 + i < g.W) ? xv[(row + w0 + i) * g.d4 + c] : zero;
+  };
+  auto stage_plane = [&](int buf) {
+    if (!active) return;
+    f32x4* dst = plane + buf * plane_f4 + ((h_ + 1) * pitch + w0 + 1) * PL_CG + cg;
+#pragma unroll
+    for (int i = 0; i < PL_P; ++i) dst[i * PL_CG] = nx[i];
+  };
+  auto store_row = [&](int t, const f32x4 (&av)[PL_P]) {
+    if (!active) return;
+    const long row = ((b * g.T + t) * g.H + h_) * g.W;
+#pragma unroll
+    for (int i = 0; i < PL_P; ++i) {
+      if (w0 + i >= g.W) continue;
+      const long o = (row + w0 + i) * g.d4 + c;
+      const f32x4 v = av[i] + bv;
+      if (y) ((f32x4*)y)[o] = v;
+      if (y16) {
+        uint2 pk;
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        ((uint2*)y16)[o] = pk;
+      }
+    }
+  };
+
+  load_plane(0);
+  __syncthreads();                                           // zero fill + weights visible
+  stage_plane(0);
+  __syncthreads();
+  for (int tp = 0; tp < g.T; ++tp) {
+    const int buf = tp & 1;
+    if (tp + 1 < g.T) load_plane(tp + 1);                    // in flight while this plane is consumed
+    const f32x4* pb = plane + buf * plane_f4;
+    int wofs = 0;
+    asm volatile("" : "+s"(wofs));                           // opaque zero: keeps the 27 weight reads inside the loop
+    const f32x4* wk = wl + wofs;                            // (hoisted they would pin 108 registers)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hp = FWD ? h_ + kh : h_ + 2 - kh;           // padded row of input row h_ + kh - 1 (FWD) / h_ - kh + 1
+      const f32x4* prow = pb + (hp * pitch + w0) * PL_CG + cg;
+      f32x4 xs[PL_P + 2];
+#pragma unroll
+      for (int i = 0; i < PL_P + 2; ++i) xs[i] = prow[i * PL_CG];
+      if (residual && kh == 1) {                             // the residual term of output time tp is this plane's centre
+#pragma unroll
+        for (int i = 0; i < PL_P; ++i) {
+          acc[FWD ? 0 : 2][i] += xs[i + 1];
+        }
+      }
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const int a = FWD ? 2 - kt : kt;
+        const f32x4 k0 = wk[((kt * 3 + kh) * 3 + 0) * PL_CG + cg], k1 = wk[((kt * 3 + kh) * 3 + 1) * PL_CG + cg],
+                     k2 = wk[((kt * 3 + kh) * 3 + 2) * PL_CG + cg];
+#pragma unroll
+        for (int i = 0; i < PL_P; ++i) {
+          if (FWD) acc[a][i] += k0 * xs[i] + k1 * xs[i + 1] + k2 * xs[i + 2];
+          else     acc[a][i] += k2 * xs[i] + k1 * xs[i + 1] + k0 * xs[i + 2];
+        }
+        // pin this (kt, kh) step: its FMAs finish here and the next LDS reads start after it -- left alone the compiler
+        // issues every LDS read of the plane up front and keeps ~300 registers live
+#pragma unroll
+        for (int i = 0; i < PL_P; ++i) asm volatile("" : "+v"(acc[a][i]) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const int tout = FWD ? tp : tp - 2;
+    if (tout >= 0) store_row(tout, acc[0]);
+#pragma unroll
+    for (int i = 0; i < PL_P; ++i) { acc[0][i] = acc[1][i]; acc[1][i] = acc[2][i]; acc[2][i] = zero; }
+    if (tp + 1 < g.T) stage_plane(buf ^ 1);
+    lds_only_barrier();
+  }
+  if (!FWD) {
+    if (g.T >= 2) store_row(g.T - 2, acc[0]);
+    store_row(g.T - 1, acc[1]);
+  }
+}
+
+// plane path geometry: threads (multiple of 64) or 0 when the plane does not fit a workgroup / LDS
+inline int plane_threads(int H, int W, int d, int* strips, size_t* lds) {
+  if (getenv("CTCLIP_PEG_SWEEP")) return 0;
+  if ((d / 4) % PL_CG) return 0;
+  const int st = (W + PL_P - 1) / PL_P;
+  const int items = H * st * PL_CG;
+  const int threads = (items + 63) / 64 * 64;
+  const size_t bytes = ((size_t)27 * PL_CG + (size_t)2 * (H + 2) * (st * PL_P + 2) * PL_CG) * sizeof(float4);
+  if (threads > PL_MAXT || bytes > 160 * 1024) return 0;
+  *strips = st;
+  *lds = bytes;
+  return threads;
+}
+
+// Weight / bias gradient on the same plane tiling.  A workgroup owns a 16-channel slice and a CHUNK of batch items; per
+// item it sweeps t keeping the x planes t-2, t-1, t in an LDS ring (each x plane is read from global memory once) and its
+// own dy values in registers; the 27 + 1 per-thread partial sums live in registers for the whole chunk, are reduced across
+// the workgroup (wave shuffles, then LDS) and leave as 448 global atomics per workgroup -- peg_bwd_weight_kernel above
+// issues 112 atomics per THREAD.
+//   dw27[kt,kh,kw][c] += sum dy[t,h,w][c] * x[t+kt-2, h+kh-1, w+kw-1][c];  dbias[c] += sum dy
+constexpr int WG_MAXT = 768;        // 12 waves -> 3 per SIMD -> 168 registers per thread
+constexpr int WG_C2 = 2 * PL_CG;    // float2 channel pairs per 16-channel slice
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__global__ __launch_bounds__(WG_MAXT) void peg_wgrad_plane_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 float* __restrict__ dw27, float* __restrict__ dbias, Grid5 g,
+                                                                 int strips, int bchunk) {
+  // one thread = 2 channels x PL_P consecutive w positions (float2 keeps the 28 accumulators at 56 registers)
+  extern __shared__ __attribute__((aligned(16))) f32x2 wg_smem[];
+  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int nslices = g.d4 / PL_CG;
+  const int d2 = g.d4 * 2;
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = blk % nslices;
+  const long b0 = (long)(blk / nslices) * bchunk, b1 = (b0 + bchunk < g.B) ? b0 + bchunk : g.B;
+  const int c2 = tid & (WG_C2 - 1), sid = tid >> 3;
+  const int h_ = sid / strips, w0 = (sid % strips) * PL_P;
+  const bool active = h_ < g.H;
+  const int pitch = strips * PL_P + 2;
+  const int plane_f2 = (g.H + 2) * pitch * WG_C2;
+  f32x2* ring = wg_smem;                                     // [3][(H+2)][pitch][WG_C2]
+  const f32x2 zero = {0.f, 0.f};
+  for (int i = tid; i < 3 * plane_f2; i += nthreads) ring[i] = zero;
+  const int c = slice * WG_C2 + c2;                          // float2 column of this thread
+  const f32x2* xv = (const f32x2*)x;
+  const f32x2* dv = (const f32x2*)dy;
+  f32x2 acc[28];
+#pragma unroll
+  for (int i = 0; i < 28; ++i) acc[i] = zero;
+  const int own = ((h_ + 1) * pitch + w0 + 1) * WG_C2 + c2;  // this thread's first interior position inside a plane
+
+  f32x2 nx[PL_P], dcur[PL_P], dnext[PL_P];
+  // x and dy share the layout: uniform plane base + one 32-bit per-thread offset (the positions follow at stride d2)
+  const uint32_t poff = (uint32_t)((h_ * g.W + w0) * d2 + c);
+  const long plane_elems = (long)g.H * g.W * d2;
+  auto load_x = [&](long b, int t) {
+    const f32x2* base = xv + (b * g.T + t) * plane_elems;
+#pragma unroll
+    for (int i = 0; i < PL_P; ++i) nx[i] = (active && w0 + i < g.W) ? base[poff + (uint32_t)(i * d2)] : zero;
+  };
+  auto load_dy = [&](long b, int t, f32x2 (&dst)[PL_P]) {
+    const f32x2* base = dv + (b * g.T + t) * plane_elems;
+#pragma unroll
+    for (int i = 0; i < PL_P; ++i) dst[i] = (active && w0 + i < g.W) ? base[poff + (uint32_t)(i * d2)] : zero;
+  };
+  auto put = [&](int slot, const f32x2 (&v)[PL_P]) {
+    if (!active) return;
+    f32x2* dst = ring + slot * plane_f2 + own;
+#pragma unroll
+    for (int i = 0; i < PL_P; ++i) dst[i * WG_C2] = v[i];
+  };
+  __syncthreads();                                           // zero fill visible (borders stay zero for good)
+
+  for (long b = b0; b < b1; ++b) {
+    load_x(b, 0);
+    load_dy(b, 0, dcur);
+    lds_only_barrier();                                      // the previous item's planes are no longer read
+    {
+      f32x2 zs[PL_P];
+#pragma unroll
+      for (int i = 0; i < PL_P; ++i) zs[i] = zero;
+      put(1, zs);                                            // x[-2] and x[-1]: the causal padding
+      put(2, zs);
+    }
+    put(0, nx);
+    lds_only_barrier();
+    for (int t = 0; t < g.T; ++t) {
+      if (t + 1 < g.T) { load_x(b, t + 1); load_dy(b, t + 1, dnext); }
+#pragma unroll
+      for (int i = 0; i < PL_P; ++i) acc[27] += dcur[i];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const f32x2* pb = ring + ((t + kt + 1) % 3) * plane_f2;      // plane t + kt - 2
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const f32x2* prow = pb + ((h_ + kh) * pitch + w0) * WG_C2 + c2;
+          f32x2 xs[PL_P + 2];
+#pragma unroll
+          for (int i = 0; i < PL_P + 2; ++i) xs[i] = prow[i * WG_C2];
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            f32x2 a = acc[(kt * 3 + kh) * 3 + kw];
+#pragma unroll
+            for (int i = 0; i < PL_P; ++i) a += dcur[i] * xs[i + kw];
+            acc[(kt * 3 + kh) * 3 + kw] = a;
+          }
+          // pin the step (see peg_plane_kernel)
+          asm volatile("" : "+v"(acc[(kt * 3 + kh) * 3 + 0]), "+v"(acc[(kt * 3 + kh) * 3 + 1]), "+v"(acc[(kt * 3 + kh) * 3 + 2]) : : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      lds_only_barrier();                                    // everybody is done with plane t-2
+      if (t + 1 < g.T) put((t + 1) % 3, nx);
+      lds_only_barrier();
+#pragma unroll
+      for (int i = 0; i < PL_P; ++i) dcur[i] = dnext[i];
+    }
+  }
+
+  // reduce the 28 partial sums over the threads that share a channel pair: lanes l ^ {8,16,32}, then the waves
+#pragma unroll
+  for (int i = 0; i < 28; ++i) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      f32x2 v = acc[i];
+      v[0] = __shfl_xor(v[0], o, 64); v[1] = __shfl_xor(v[1], o, 64);
+      acc[i] += v;
+    }
+  }
+  __syncthreads();                                           // ring is free
+  f32x2* red = wg_smem;                                      // [waves][WG_C2][28]
+  if (lane < WG_C2) {
+#pragma unroll
+    for (int i = 0; i < 28; ++i) red[(wave * WG_C2 + lane) * 28 + i] = acc[i];
+  }
+  __syncthreads();
+  const int nwaves = nthreads >> 6;
+  for (int idx = tid; idx < WG_C2 * 28; idx += nthreads) {
+    const int rc = idx / 28, i = idx % 28;
+    f32x2 sum = zero;
+    for (int wv = 0; wv < nwaves; ++wv) sum += red[(wv * WG_C2 + rc) * 28 + i];
+    float* dst = (i < 27) ? dw27 + ((long)i * d2 + slice * WG_C2 + rc) * 2 : dbias + (slice * WG_C2 + rc) * 2;
+    atomicAdd(dst + 0, sum[0]); atomicAdd(dst + 1, sum[1]);
+  }
+}
+
+inline int wgrad_plane_threads(int H, int W, int d, int* strips, size_t* lds) {
+  if (getenv("CTCLIP_PEG_SWEEP")) return 0;
+  if ((d / 4) % PL_CG) return 0;
+  const int st = (W + PL_P - 1) / PL_P;
+  const int threads = (H * st * WG_C2 + 63) / 64 * 64;
+  size_t bytes = (size_t)3 * (H + 2) * (st * PL_P + 2) * WG_C2 * sizeof(float2);
+  const size_t red = (size_t)(threads / 64) * WG_C2 * 28 * sizeof(float2);
+  if (bytes < red) bytes = red;
+  if (threads > WG_MAXT || bytes > 160 * 1024) return 0;
+  *strips = st;
+  *lds = bytes;
+  return threads;
+}
+
 inline unsigned grid_for(long work) {
   long b = (work + 255) / 256;
   if (b < 1) b = 1;
@@ -189,6 +478,17 @@ int ctclip_peg_fwd(const float* x, const float* w27, const float* bias, float* y
   if (B * T * H * W <= 0) return 0;
   if (d & 3) return (int)hipErrorInvalidValue;
   Grid5 g{B, T, H, W, d / 4};
+  {
+    int strips = 0;
+    size_t plds = 0;
+    const int threads = plane_threads(H, W, d, &strips, &plds);
+    if (threads > 0 && B * (g.d4 / PL_CG) < (1L << 30)) {
+      if (plds > 65536) hipFuncSetAttribute((const void*)peg_plane_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+      hipLaunchKernelGGL(peg_plane_kernel<true>, dim3((unsigned)(B * (g.d4 / PL_CG))), dim3(threads), plds, (hipStream_t)stream,
+                         x, w27, bias, y, (bf16_t*)y_bf16, g, residual, strips);
+      CTCLIP_CHECK_LAUNCH();
+    }
+  }
   const size_t lds = (size_t)27 * d * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   if (lds > 65536) hipFuncSetAttribute((const void*)peg_sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -202,6 +502,17 @@ int ctclip_peg_bwd_data(const float* dy, const float* w27, float* dx, void* dx_b
   if (B * T * H * W <= 0) return 0;
   if (d & 3) return (int)hipErrorInvalidValue;
   Grid5 g{B, T, H, W, d / 4};
+  {
+    int strips = 0;
+    size_t plds = 0;
+    const int threads = plane_threads(H, W, d, &strips, &plds);
+    if (threads > 0 && B * (g.d4 / PL_CG) < (1L << 30)) {
+      if (plds > 65536) hipFuncSetAttribute((const void*)peg_plane_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+      hipLaunchKernelGGL(peg_plane_kernel<false>, dim3((unsigned)(B * (g.d4 / PL_CG))), dim3(threads), plds, (hipStream_t)stream,
+                         dy, w27, (const float*)nullptr, dx, (bf16_t*)dx_bf16, g, residual, strips);
+      CTCLIP_CHECK_LAUNCH();
+    }
+  }
   const size_t lds = (size_t)27 * d * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   if (lds > 65536) hipFuncSetAttribute((const void*)peg_sweep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -216,6 +527,29 @@ int ctclip_peg_bwd_weight(const float* dy, const float* x, float* dw27, float* d
   if (npos <= 0) return 0;
   if ((d & 3) || d / 4 > 256) return (int)hipErrorInvalidValue;
   Grid5 g{B, T, H, W, d / 4};
+  {
+    int strips = 0;
+    size_t plds = 0;
+    const int threads = wgrad_plane_threads(H, W, d, &strips, &plds);
+    if (threads > 0) {
+      // ~2 rounds of one-per-CU workgroups; more batch items per workgroup = fewer atomics
+      static const int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+      }();
+      const int nslices = g.d4 / PL_CG;
+      long nchunks = (2L * ncu) / nslices;
+      if (nchunks < 1) nchunks = 1;
+      if (nchunks > B) nchunks = B;
+      const int bchunk = (int)((B + nchunks - 1) / nchunks);
+      nchunks = (B + bchunk - 1) / bchunk;
+      if (plds > 65536) hipFuncSetAttribute((const void*)peg_wgrad_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+      hipLaunchKernelGGL(peg_wgrad_plane_kernel, dim3((unsigned)(nchunks * nslices)), dim3(threads), plds, (hipStream_t)stream,
+                         dy, x, dw27, dbias, g, strips, bchunk);
+      CTCLIP_CHECK_LAUNCH();
+    }
+  }
   hipLaunchKernelGGL(peg_bwd_weight_kernel, dim3(grid_for(B * H * ((W + PEG_CWW - 1) / PEG_CWW) * g.d4)), dim3(256), 0,
                      (hipStream_t)stream, dy, x, dw27, dbias, g);
   CTCLIP_CHECK_LAUNCH();

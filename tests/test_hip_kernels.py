@@ -291,6 +291,46 @@ def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask, monkeypatch):
         check("attn dbias 2-D grid table", dt2, ref2, 3e-2)
 
 
+# ---------------------------------------------------------------------------------------------- PEG
+@pytest.mark.parametrize("B,T,H,W,d", [
+    (2, 5, 24, 24, 32),      # the CT-ViT plane: 4 strips of 6 per row, 384 threads
+    (3, 1, 4, 7, 16),        # single time step, ragged strip (7 = 6 + 1)
+    (1, 2, 3, 5, 48),        # T = 2: the backward drain stores both remaining planes
+    (2, 4, 9, 13, 16),       # odd plane
+    (1, 3, 30, 30, 16),      # plane too large for one workgroup -> generic sweep kernel
+    (2, 3, 4, 5, 8),         # d/4 not a multiple of the channel slice -> generic sweep kernel
+])
+@pytest.mark.parametrize("residual", [0, 1])
+def test_peg_kernels(hip, B, T, H, W, d, residual):
+    """reference src/utils/attention.py:55-83 (+ the residual of :325): causal depthwise 3x3x3 convolution"""
+    x = rnd(B, T, H, W, d, seed=40)
+    wt = rnd(d, 1, 3, 3, 3, seed=41) * 0.3
+    bias = rnd(d, seed=42)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    xp = torch.nn.functional.pad(xr.permute(0, 4, 1, 2, 3), (1, 1, 1, 1, 2, 0))
+    ref = torch.nn.functional.conv3d(xp, wr, br, groups=d).permute(0, 2, 3, 4, 1)
+    if residual:
+        ref = ref + xr
+    w27 = wt.reshape(d, 27).t().contiguous()
+    y = torch.empty_like(x)
+    y16 = torch.empty(x.shape, device=DEV, dtype=torch.bfloat16)
+    hip.peg_fwd(x, w27, bias, y, y16, B, T, H, W, d, residual)
+    check("peg y", y, ref, 1e-5)
+    check("peg y16", y16, ref, 1e-2)
+    dy = rnd(B, T, H, W, d, seed=43)
+    ref.backward(dy)
+    dx = torch.empty_like(x)
+    dx16 = torch.empty(x.shape, device=DEV, dtype=torch.bfloat16)
+    hip.peg_bwd_data(dy, w27, dx, dx16, B, T, H, W, d, residual)
+    check("peg dx", dx, xr.grad, 1e-5)
+    check("peg dx16", dx16, xr.grad, 1e-2)
+    dw27 = torch.zeros(27, d, device=DEV)
+    db = torch.zeros(d, device=DEV)
+    hip.peg_bwd_weight(dy, x, dw27, db, B, T, H, W, d)
+    check("peg dw", dw27.t().reshape(d, 1, 3, 3, 3), wr.grad, 1e-4)
+    check("peg db", db, br.grad, 1e-4)
+
+
 # ---------------------------------------------------------------------------------------------- elementwise
 def test_elementwise(hip):
     rows, I = 50, 152
