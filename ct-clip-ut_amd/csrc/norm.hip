@@ -69,10 +69,18 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy
-template <int LN_NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// DY16: dy is bf16 (the output of a bf16 data-gradient GEMM) and `dres2` is an optional second, bf16, residual-path term
+__device__ __forceinline__ float4 ld_bf16x4(const bf16_t* p) {
+  const uint2 v = *(const uint2*)p;
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+
+template <int LN_NV, bool DY16>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy_any, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                            const bf16_t* __restrict__ dres2,
                                                             float* __restrict__ dx, bf16_t* __restrict__ dx16,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int rows, int dim) {
@@ -92,14 +100,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int row = wave_global; row < rows; row += nwaves) {
     const float mu = mean[row], rs = rstd[row];
     const float4* xr = (const float4*)(x + (long)row * dim);
-    const float4* dr = (const float4*)(dy + (long)row * dim);
+    const float4* dr = (const float4*)((const float*)dy_any + (long)row * dim);
+    const bf16_t* dr16 = (const bf16_t*)dy_any + (long)row * dim;
     float4 xh[LN_NV], gg[LN_NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_NV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
-        const float4 xv = xr[c], dv = dr[c], gm = ((const float4*)gamma)[c];
+        const float4 xv = xr[c], dv = DY16 ? ld_bf16x4(dr16 + 4 * c) : dr[c], gm = ((const float4*)gamma)[c];
         xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         gg[i] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
         s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
@@ -120,6 +129,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         o.w = rs * (gg[i].w - m1 - xh[i].w * m2);
         if (dres) {
           const float4 r = ((const float4*)(dres + (long)row * dim))[c];
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (DY16 && dres2) {
+          const float4 r = ld_bf16x4(dres2 + (long)row * dim + 4 * c);
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         if (dx) ((float4*)(dx + (long)row * dim))[c] = o;
@@ -272,11 +285,28 @@ int ctclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
   if (blocks > 1024) blocks = 1024;
   const size_t lnlds = (size_t)2 * dim * sizeof(float);
 #define LN_BWD(NV)                                                                                                      \
-  hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(blocks), dim3(256), lnlds, (hipStream_t)stream, dy, x, gamma, mean, \
-                     rstd, dres, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim)
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NV, false>), dim3(blocks), dim3(256), lnlds, (hipStream_t)stream, (const void*)dy, x, \
+                     gamma, mean, rstd, dres, (const bf16_t*)nullptr, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim)
   const int nv = (dim / 4 + 63) / 64;
   if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(16);
 #undef LN_BWD
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              const float* dres, const void* dres2_bf16, float* dx, void* dx_bf16, float* dgamma,
+                              float* dbeta, int rows, int dim, void* stream) {
+  if (rows <= 0) return 0;
+  if ((dim & 3) || dim > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  const size_t lnlds = (size_t)2 * dim * sizeof(float);
+#define LN_BWD16(NV)                                                                                                    \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NV, true>), dim3(blocks), dim3(256), lnlds, (hipStream_t)stream, dy_bf16, x, gamma, \
+                     mean, rstd, dres, (const bf16_t*)dres2_bf16, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim)
+  const int nv = (dim / 4 + 63) / 64;
+  if (nv <= 1) LN_BWD16(1); else if (nv <= 2) LN_BWD16(2); else if (nv <= 3) LN_BWD16(3); else if (nv <= 4) LN_BWD16(4); else LN_BWD16(16);
+#undef LN_BWD16
   CTCLIP_CHECK_LAUNCH();
 }
 

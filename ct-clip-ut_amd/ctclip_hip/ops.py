@@ -347,12 +347,14 @@ class AttentionFn(Function):
             wgrad(dyb, o, dim, inner, M, out=gwo)
             hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, inner, inner, float(scale))
             hip.headnorm_bwd(dkh, kv, kinv, sh["k_scale"], dkv, gks, M, heads, dp, inner, 2 * inner, 2 * inner, 1.0)
-            dn1 = dgrad(dq, sh["wq"], M, inner, dim, wT16=sh.get("wqT"))
+            # both data gradients leave their (store-bound, K = 256 / 512) GEMMs in bf16; the f32 residual-path gradient
+            # dy2 is added inside the LayerNorm backward, so the residual stream itself never passes through bf16
+            dn1 = dgrad(dq, sh["wq"], M, inner, dim, out_dtype=BF16, wT16=sh.get("wqT"))
             wgrad(dq, n1, inner, dim, M, out=gwq)
-            dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None, wT16=sh.get("wkvT"))
+            dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, out_dtype=BF16, wT16=sh.get("wkvT"))
             wgrad(dkv, xb, 2 * inner, dim, M, out=gwkv)
             dx16 = torch.empty(M, dim, dtype=BF16, device=dev)
-            hip.layernorm_bwd(dn1, x2, gamma, mean, rstd, dxkv, dx, dx16, gg, None, M, dim)
+            hip.layernorm_bwd_bf16(dn1, x2, gamma, mean, rstd, dy2 if residual else None, dxkv, dx, dx16, gg, None, M, dim)
             return (_tag16(dx.reshape(nseq, n, dim), dx16), _ret(gg, d6), _ret(gwq, d3), _ret(gwkv, d4), _ret(gqs, d1), _ret(gks, d2),
                     _ret(gwo, d5), dbias, None, None, None)
         dwout = wgrad(dyb, o, dim, inner, M)
@@ -412,12 +414,12 @@ class FeedForwardFn(Function):
         wgrad(dyb, g, dim, I, M, out=gw2)                          # g's zero pad columns I..Ip-1 are simply not produced
         dh = torch.empty_like(h)
         hip.geglu_bwd(dg, h, dh, M, Ip, Ip, 2 * Ip)
-        dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim, wT16=sh.get("w1T"))
+        dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim, out_dtype=BF16, wT16=sh.get("w1T"))
         wgrad(dh, n2, I, dim, M, out=gw1[:I])                      # value half  (rows 0..I-1 of the reference weight)
         wgrad(dh[:, Ip:], n2, I, dim, M, out=gw1[I:])              # gate half   (rows I..2I-1)
         dx = torch.empty(M, dim, dtype=F32, device=dy.device)
         dx16 = torch.empty(M, dim, dtype=BF16, device=dy.device)
-        hip.layernorm_bwd(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, dx, dx16, glw, glb, M, dim)
+        hip.layernorm_bwd_bf16(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, None, dx, dx16, glw, glb, M, dim)
         return _tag16(dx.reshape(dy.shape), dx16), _ret(glw, d3), _ret(glb, d4), _ret(gw1, d1), _ret(gw2, d2), None, None
 
 

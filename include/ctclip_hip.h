@@ -50,6 +50,12 @@ int ctclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 int ctclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                          const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int rows, int dim,
                          void* stream);
+/* same with the LN-path gradient in bf16 (the output of a bf16 data-gradient GEMM) and an optional second, bf16,
+ * residual-path term: dx = dres + dres2 + LN'(dy).  (the K/V projection of attention.py:138 reads the un-normalised x, so
+ * its data gradient by-passes LN'.) */
+int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              const float* dres, const void* dres2_bf16, float* dx, void* dx_bf16, float* dgamma,
+                              float* dbeta, int rows, int dim, void* stream);
 
 /* ---- per-head cosine normalisation: y = x/|x| * scale[d] * mult   (attention.py:151-153,155) ---- */
 int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_norm, long rows, int heads, int dhead,

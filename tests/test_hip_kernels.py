@@ -181,6 +181,19 @@ def test_layernorm_fwd_bwd(hip, rows, dim, with_beta):
     check("ln dgamma", dg, gm.grad, 2e-5)
     if with_beta:
         check("ln dbeta", db, bt.grad, 2e-5)
+    # bf16 LN-path gradient + f32 residual term + bf16 second residual term: exact in the bf16-rounded inputs
+    dy16, dres2 = bf(dy), bf(rnd(rows, dim, seed=14))
+    x.grad = None
+    gm.grad = None
+    torch.nn.functional.layer_norm(x, (dim,), gm, bt, 1e-5).backward(dy16.float())
+    dg2, db2 = torch.zeros(dim, device=DEV), torch.zeros(dim, device=DEV)
+    hip.layernorm_bwd_bf16(dy16, x.detach(), gm.detach(), mean, rstd, dres, dres2, dx, dx16, dg2, db2 if with_beta else None,
+                           rows, dim)
+    check("ln16 dx", dx, x.grad + dres + dres2.float(), 2e-5)
+    check("ln16 dx16", dx16, x.grad + dres + dres2.float(), 1e-2)
+    check("ln16 dgamma", dg2, gm.grad, 2e-5)
+    hip.layernorm_bwd_bf16(dy16, x.detach(), gm.detach(), mean, rstd, None, None, dx, None, dg2, None, rows, dim)
+    check("ln16 dx (no residual terms)", dx, x.grad, 2e-5)
 
 
 @pytest.mark.parametrize("D", [32, 64])

@@ -7,20 +7,25 @@ from ctclip_hip.lib import hip
 
 B = int(os.environ.get("B", 8))
 T = 13824 * B
-shapes = [  # name, M, N, K, akm, bkm, c_fp32, split, accumulate
+shapes = [  # name, M, N, K, akm, bkm, c_fp32, split, accumulate   (I = 1365, padded Ip = 1408)
     ("sq4096", 4096, 4096, 4096, 1, 1, 0, 1, 0),
     ("sq8192", 8192, 8192, 8192, 1, 1, 0, 1, 0),
-    ("ff1 fwd", T, 2736, 512, 1, 1, 0, 1, 0),
-    ("ff2 fwd(+res f32)", T, 512, 1368, 1, 1, 1, 1, 0),
+    ("ff1 fwd", T, 2816, 512, 1, 1, 0, 1, 0),
+    ("ff2 fwd f32", T, 512, 1408, 1, 1, 1, 1, 0),
     ("q fwd", T, 256, 512, 1, 1, 0, 1, 0),
     ("kv fwd", T, 512, 512, 1, 1, 0, 1, 0),
     ("out fwd f32", T, 512, 256, 1, 1, 1, 1, 0),
     ("patch fwd f32", T, 512, 4000, 1, 1, 1, 1, 0),
-    ("ff2 dgrad", T, 1368, 512, 1, 0, 0, 1, 0),
-    ("ff1 dgrad f32", T, 512, 2736, 1, 0, 1, 1, 0),
-    ("ff1 wgrad", 2736, 512, T, 0, 0, 1, 0, 1),
-    ("ff2 wgrad", 512, 1368, T, 0, 0, 1, 0, 1),
+    ("ff2 dgrad", T, 1408, 512, 1, 1, 0, 1, 0),
+    ("ff1 dgrad f32", T, 512, 2816, 1, 1, 1, 1, 0),
+    ("out dgrad", T, 256, 512, 1, 1, 0, 1, 0),
+    ("q dgrad f32", T, 512, 256, 1, 1, 1, 1, 0),
+    ("kv dgrad f32", T, 512, 512, 1, 1, 1, 1, 0),
+    ("ff1 wgrad half", 1365, 512, T, 0, 0, 1, 0, 1),
+    ("ff2 wgrad", 512, 1365, T, 0, 0, 1, 0, 1),
     ("kv wgrad", 512, 512, T, 0, 0, 1, 0, 1),
+    ("q wgrad", 256, 512, T, 0, 0, 1, 0, 1),
+    ("patch wgrad", 512, 4000, T, 0, 0, 1, 0, 1),
 ]
 dev = "cuda"
 only = os.environ.get("ONLY")
@@ -31,8 +36,8 @@ for name, M, N, K, akm, bkm, cf, split, acc in shapes:
     Bm = torch.randn((N, K) if bkm else (K, N), device=dev).to(torch.bfloat16)
     C = torch.zeros(M, N, device=dev, dtype=torch.float32 if cf else torch.bfloat16)
     if split == 0:
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        split = max(1, min((K + 63) // 64, (1024 + tiles - 1) // tiles))
+        from ctclip_hip.ops import _splits_for
+        split = _splits_for(M, N, K)
     ACT = int(os.environ.get("ACT", 0))
     LDC = N if not os.environ.get("LDC0") else 0
     def run():
