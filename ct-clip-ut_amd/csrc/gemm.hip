@@ -421,6 +421,8 @@ bool bad_layout(const void* p, long ld, int contiguous_extent, bool kmajor) {
 int ctclip_gemm2_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                         long lda, long ldb, long ldc, long ldr, int a_kmajor, int b_kmajor, int c_fp32, int split_k,
                         int accumulate, float alpha, int act, hipStream_t st);
+int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
+                        long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, hipStream_t st);
 
 extern "C" {
 
@@ -441,6 +443,13 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
     // path with small shapes); CTCLIP_GEMM_V1=1 disables the pipelined kernel.
     static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
     static const bool force_v1 = getenv("CTCLIP_GEMM_V1") != nullptr;
+    // k-major x k-major products with many 256 x 256 tiles (every forward / data-gradient projection over all tokens) go
+    // to the deeper, more compute-dense gemm3.hip.  CTCLIP_GEMM_NO_V3=1 disables it.
+    static const bool no_v3 = getenv("CTCLIP_GEMM_NO_V3") != nullptr;
+    const long blocks3 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    if (!no_v3 && !force_v1 && a_kmajor && b_kmajor && (K % 32) == 0 && split_k <= 1 && !accumulate &&
+        (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
+      return ctclip_gemm3_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, (hipStream_t)stream);
     const long blocks2 = (long)((M + 255) / 256) * ((N + 127) / 128) * (split_k > 1 ? split_k : 1);
     const bool eligible = !force_v1 && (K % 64) == 0 && blocks2 >= 192;
     if (eligible || (v2_all && !force_v1 && (K % 64) == 0 && blocks2 >= 8))

@@ -1,0 +1,254 @@
+// bf16 MFMA GEMM, 256 x 256 tile variant for the k-major x k-major products of the CT-CLIP step (every forward and
+// data-gradient projection: C[M,N] = A[M,K] B[N,K]^T with M = all tokens).
+//
+// gemm2.hip (256 x 128 x 64, 64 x 64 per wave) tops out near 40 % of the MFMA peak: each CU has to pull 48 KiB through
+// L2 -> LDS for every 1024 matrix-pipe cycles and only two stages (96 KiB) can be in flight, so with ~1-2 us of loaded
+// L2/HBM latency the ring runs dry (profiles/r01_gemm_pmc.txt: matrix pipe 28 % busy, LDS 37 %, waves waiting 43 %).
+// This kernel trades tile shape for bytes per flop and depth:
+//   * block tile 256 x 256 x 32, 512 threads = 8 waves (2 x 4), each wave 128 x 64 as 4x2 MFMA 32x32x16
+//     (128 FLOP per operand byte instead of 85; 6 KiB of LDS fragment reads per 8 MFMAs instead of 4 KiB per 4);
+//   * a FOUR-stage ring of 32 KiB stages (128 KiB): three K-steps in flight ahead of the one being consumed;
+//   * global_load_lds (16 B per lane) with the bank swizzle on the SOURCE address, counted `s_waitcnt vmcnt(8)` and one
+//     raw s_barrier per K-step, as in gemm2.hip;
+//   * epilogue through the ring as f32 [128][256] halves -> 16-byte coalesced stores (bias / residual / GELU fused).
+// Preconditions (checked by the dispatcher in gemm.hip): both operands k-major, K % 32 == 0, no split-K / accumulate.
+#include "common.h"
+#include <stdlib.h>
+
+namespace g3 {
+
+constexpr int BM = 256, BK = 32;
+constexpr int SUB = 16384;                 // the A tile of a stage: 256 x 32 bf16 (the B tile follows it)
+
+struct Args {
+  const bf16_t* A; const bf16_t* B; void* C; const float* bias; const float* resid;
+  long lda, ldb, ldc, ldr;
+  int M, N, K, tiles_m, tiles_n, c_fp32, act;
+  float alpha;
+};
+
+// [256 rows][32 k] bf16 tile, 64-byte rows, 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128 phase
+// (16 consecutive rows, same logical chunk) hit 16 different bank groups
+__device__ __forceinline__ uint32_t tile_off(int r, int chunk) { return (uint32_t)(r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4)); }
+
+__device__ __forceinline__ bf16x8 read_frag(const char* tile, int rbase, int s, int lane) {
+  const int r = rbase + (lane & 31);
+  return *(const bf16x8*)(tile + tile_off(r, 2 * s + (lane >> 5)));
+}
+
+// element offset (from the operand base, at k-tile 0) of the 16 bytes lane `lane` contributes to 1 KiB piece `p`
+// (rows 16p .. 16p+15, 4 chunks each) of the tile whose first row is r0; its LDS destination is piece_base + lane*16
+__device__ __forceinline__ long piece_src(int p, int lane, int r0, int R, long ld) {
+  const int r = 16 * p + (lane >> 2), pc = lane & 3, c = pc ^ ((r >> 2) & 3);
+  int row = r0 + r;
+  if (row >= R) row = R - 1;                       // masked in the epilogue
+  return (long)row * ld + c * 8;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+#define G3_GLDS(gptr, ldsoff)                                                                                     \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                          \
+                                   (__attribute__((address_space(3))) void*)(uintptr_t)(ldsoff), 16, 0, 0)
+
+// BN = 256: 8 waves (2 x 4), 4-stage ring of 32 KiB, one workgroup per CU.
+// BN = 128: 4 waves (2 x 2), 3-stage ring of 24 KiB = 72 KiB, TWO workgroups per CU: vmcnt is an in-order counter, so a
+//           wave cannot see its next tile's LDS-DMAs complete before its own epilogue stores have drained to HBM; with two
+//           independent workgroups one computes while the other writes back and refills its ring.
+template <int BN, int NS>
+__global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
+  constexpr int WN = BN / 64, NT = 2 * WN * 64;
+  constexpr int STAGE = SUB + BN * BK * 2;
+  constexpr int PPW = (STAGE / 1024) / (2 * WN);   // LDS-DMA pieces of 1 KiB per wave and stage: 4 (BN 256) or 6 (BN 128)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % g.tiles_n;
+  const int tm = bid / g.tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+  const int nk = g.K / BK;
+
+  // piece q = wave * PPW + j of a stage: the first 16 are the A tile, the rest the B tile (stored right behind it)
+  const bf16_t* src[PPW];
+  uint32_t dst[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int q = wave * PPW + j;
+    src[j] = (q < 16) ? g.A + piece_src(q, lane, row0, g.M, g.lda) : g.B + piece_src(q - 16, lane, col0, g.N, g.ldb);
+    dst[j] = (uint32_t)(q * 1024);
+  }
+  auto issue_part = [&](int t, int j0) {           // PPW/2 of this wave's pieces of K-step t -> stage t % NS
+    const uint32_t sb = lds0 + (uint32_t)((t % NS) * STAGE);
+#pragma unroll
+    for (int j = j0; j < j0 + PPW / 2; ++j) G3_GLDS(src[j] + (long)t * BK, sb + dst[j]);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < nk) { issue_part(t, 0); issue_part(t, PPW / 2); }
+
+  for (int t = 0; t < nk; ++t) {
+    // K-step t must have landed; the PPW LDS-DMAs of each of the (up to NS-2) younger steps may stay in flight across the barrier
+    const int younger = nk - 1 - t;
+    if (NS == 4) {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                  // also: every wave is done reading stage (t+3) % NS (K-step t-1)
+    const bool pre = t + NS - 1 < nk && !(g.act & 0x200);   // 0x200: timing experiment, no operand traffic after the prologue
+    const char* sa = smem + (t % NS) * STAGE;
+    const char* sb = sa + SUB;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag(sa, wm * 128 + i * 32, s, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag(sb, wn * 64 + j * 32, s, lane);
+      if (pre) issue_part(t + NS - 1, s * (PPW / 2));   // the next ring slot, half of the pieces between the MFMA groups
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+    }
+  }
+
+  // epilogue: two 128-row halves through the ring (f32 [128][BN]: 128 / 64 KiB); half h is owned by the waves with wm == h
+  const int half = lane >> 5, lc = lane & 31;
+  float* ct = (float*)smem;
+  const int act = g.act & 0xff;
+#pragma unroll 1
+  for (int hh = 0; hh < 2; ++hh) {
+    __syncthreads();                               // fragment reads of the last stage / the other half's stores are done
+    if (wm == hh) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ct[(i * 32 + acc_row(r, half)) * BN + wn * 64 + j * 32 + lc] = acc[i][j][r];
+    }
+    __syncthreads();
+    const int hrow0 = row0 + hh * 128;
+    if (g.c_fp32) {
+      float* C = (float*)g.C;
+      const bool vec = ((g.ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0) &&
+                       (!g.resid || (((g.ldr & 3) == 0) && ((((uintptr_t)g.resid) & 15) == 0)));
+#pragma unroll 4
+      for (int it = 0; it < (128 * BN / 4) / NT; ++it) {
+        const int id = it * NT + tid, r = id / (BN / 4), c4 = (id % (BN / 4)) * 4;
+        const int row = hrow0 + r, col = col0 + c4;
+        if (row >= g.M || col >= g.N) continue;
+        const float4 t = *(const float4*)(ct + r * BN + c4);
+        float v[4] = {t.x * g.alpha, t.y * g.alpha, t.z * g.alpha, t.w * g.alpha};
+        if (vec && col + 3 < g.N) {
+          if (g.bias) { const float4 b = *(const float4*)(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+          if (g.resid) { const float4 q = *(const float4*)(g.resid + (long)row * g.ldr + col); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+          if (act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+          *(float4*)(C + (long)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          for (int e = 0; e < 4 && col + e < g.N; ++e) {
+            float x = v[e] + (g.bias ? g.bias[col + e] : 0.f);
+            if (g.resid) x += g.resid[(long)row * g.ldr + col + e];
+            if (act == 1) x = gelu_erf(x);
+            C[(long)row * g.ldc + col + e] = x;
+          }
+        }
+      }
+    } else {
+      bf16_t* C = (bf16_t*)g.C;
+      const bool vec = ((g.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0) &&
+                       (!g.resid || (((g.ldr & 3) == 0) && ((((uintptr_t)g.resid) & 15) == 0)));
+#pragma unroll 4
+      for (int it = 0; it < (128 * BN / 8) / NT; ++it) {
+        const int id = it * NT + tid, r = id / (BN / 8), c8 = (id % (BN / 8)) * 8;
+        const int row = hrow0 + r, col = col0 + c8;
+        if (row >= g.M || col >= g.N) continue;
+        const float4 t0 = *(const float4*)(ct + r * BN + c8), t1 = *(const float4*)(ct + r * BN + c8 + 4);
+        float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+        if (vec && col + 7 < g.N) {
+          if (g.bias) {
+            const float4 b0 = *(const float4*)(g.bias + col), b1 = *(const float4*)(g.bias + col + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+          }
+          if (g.resid) {
+            const float4 q0 = *(const float4*)(g.resid + (long)row * g.ldr + col), q1 = *(const float4*)(g.resid + (long)row * g.ldr + col + 4);
+            v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
+          }
+          if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+          }
+          uint4 o;
+          o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+          *(uint4*)(C + (long)row * g.ldc + col) = o;
+        } else {
+          for (int e = 0; e < 8 && col + e < g.N; ++e) {
+            float x = v[e] + (g.bias ? g.bias[col + e] : 0.f);
+            if (g.resid) x += g.resid[(long)row * g.ldr + col + e];
+            if (act == 1) x = gelu_erf(x);
+            C[(long)row * g.ldc + col + e] = f32_to_bf16(x);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace g3
+
+// called by ctclip_gemm_bf16 (gemm.hip): k-major x k-major, K % 32 == 0, plain (non-accumulating) output
+int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
+                        long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, hipStream_t st) {
+  using namespace g3;
+  // 256 x 256 (one workgroup per CU, 4 stages) is the default: equal to the 256 x 128 / two-workgroup form at K = 512 and
+  // 5-10 % ahead at K >= 1408 (profiles/r01_gemm_v3.txt).  CTCLIP_GEMM3_BN=128 selects the latter.
+  static const int variant = [] {
+    const char* e = getenv("CTCLIP_GEMM3_BN");
+    return (e && atoi(e) == 128) ? 128 : 256;
+  }();
+  const int bn = variant;
+  Args g{};
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + bn - 1) / bn;
+  g.c_fp32 = c_fp32; g.act = act; g.alpha = alpha;
+  if (bn == 256) {
+    const size_t lds = (size_t)4 * (SUB + 256 * BK * 2);   // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm3_kernel<256, 4>), dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
+  } else {
+    const size_t lds = (size_t)3 * (SUB + 128 * BK * 2);   // 72 KiB: two workgroups per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm3_kernel<128, 3>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, st, g);
+  }
+  return (int)hipGetLastError();
+}

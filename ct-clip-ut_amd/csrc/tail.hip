@@ -277,3 +277,38 @@ int ctclip_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// diagnostic: register-resident MFMA loop (no memory traffic) -- what the matrix pipes sustain at the clock the part
+// actually holds under this load; bench / DESIGN quote roofline fractions against the datasheet peak, this probe shows
+// how much of the gap is power management rather than the kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(512) void mfma_probe_kernel(float* __restrict__ out, int iters) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x + j)); b[j] = (__bf16)(0.002f * (threadIdx.x - j)); }
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = mfma32(a, b, acc[i]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 123.456f) out[0] = s;                   // keep the loop alive
+}
+}  // namespace
+
+extern "C" int ctclip_probe_mfma(float* out, int blocks, int iters, void* stream) {
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
+  CTCLIP_CHECK_LAUNCH();
+}

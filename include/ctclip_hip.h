@@ -162,6 +162,10 @@ int ctclip_bert_embed_fwd(const long* ids, const long* token_type, const float* 
 int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* dy, float* dword, float* dpos,
                           float* dtype, long rows, int L, int hidden, void* stream);
 
+/* ---- diagnostic: register-resident MFMA 32x32x16 bf16 loop, blocks x 512 threads x iters x 16 MFMAs per wave; times
+ * what the matrix pipes sustain at the clock the part holds under load (no reference counterpart) ---- */
+int ctclip_probe_mfma(float* out, int blocks, int iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

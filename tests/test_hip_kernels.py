@@ -62,7 +62,10 @@ def test_gemm_layouts(hip, akm, bkm, M, N, K):
 
 
 @pytest.mark.parametrize("akm,bkm", [(1, 1), (1, 0), (0, 0), (0, 1)])
-@pytest.mark.parametrize("M,N,K,split", [(4096, 1536, 256, 1), (4000, 1496, 192, 1), (520, 392, 8192, 16), (3000, 640, 64, 1)])
+@pytest.mark.parametrize("M,N,K,split", [(4096, 1536, 256, 1), (4000, 1496, 192, 1), (520, 392, 8192, 16), (3000, 640, 64, 1),
+                                         (20000, 1408, 512, 1),   # 869 tiles > CUs: persistent walk, ragged last row tile
+                                         (16384, 2048, 128, 1),   # persistent, two K-steps per tile, all tiles interior
+                                         (9000, 1104, 64, 1)])    # persistent, one K-step per tile, ragged in both directions
 def test_gemm_pipelined_variant(hip, akm, bkm, M, N, K, split):
     """Shapes large enough (and K % 64 == 0) to dispatch to the LDS-DMA pipelined kernel (csrc/gemm2.hip), including
     ragged M/N tiles, the one-k-tile case, and split-K accumulation.  CTCLIP_GEMM_V2_ALL is set by conftest for the gpu
