@@ -415,8 +415,11 @@ class FeedForwardFn(Function):
         dh = torch.empty_like(h)
         hip.geglu_bwd(dg, h, dh, M, Ip, Ip, 2 * Ip)
         dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim, out_dtype=BF16, wT16=sh.get("w1T"))
-        wgrad(dh, n2, I, dim, M, out=gw1[:I])                      # value half  (rows 0..I-1 of the reference weight)
-        wgrad(dh[:, Ip:], n2, I, dim, M, out=gw1[I:])              # gate half   (rows I..2I-1)
+        # one product over all 2*Ip columns of dh (the pad columns are zero): n2 is streamed once and 2*Ip = 2816 is a
+        # whole number of 256-row tiles, where two I = 1365-row products each round up to six
+        gw1p = wgrad(dh, n2, 2 * Ip, dim, M)
+        gw1[:I] += gw1p[:I]                                        # value half  (rows 0..I-1 of the reference weight)
+        gw1[I:] += gw1p[Ip:Ip + I]                                 # gate half   (rows I..2I-1)
         dx = torch.empty(M, dim, dtype=F32, device=dy.device)
         dx16 = torch.empty(M, dim, dtype=BF16, device=dy.device)
         hip.layernorm_bwd_bf16(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, None, dx, dx16, glw, glb, M, dim)
