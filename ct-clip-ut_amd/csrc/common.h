@@ -31,6 +31,24 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// ----- erf / exact (erf) GELU -----------------------------------------------------------------
+// Abramowitz-Stegun 7.1.26: |error| <= 1.5e-7 over the whole real line -- three orders of magnitude below bf16
+// resolution -- in ~14 issue slots (one v_rcp, one v_exp) instead of the ~50-instruction branchy libm erff.  The GELUs
+// of this path (GEGLU attention.py:38-41, BertIntermediate) sit in GEMM epilogues and HBM-bound sweeps where that
+// difference is exposed time.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  const float y = fmaf(-p * t, e, 1.0f);
+  return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_erf_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+
 // ----- wave-level reductions (64 lanes) -------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -4,9 +4,10 @@
 
 namespace {
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_f(float x) { return gelu_erf_fast(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f)) +
+         x * 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
 }
 __device__ __forceinline__ void unpack8(const uint4& r, float (&f)[8]) {
   const uint32_t w[4] = {r.x, r.y, r.z, r.w};
@@ -31,16 +32,20 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
   }
 }
 
-// GEGLU, reference src/utils/attention.py:38-41: h = [val | gate] halves of width I; g = gelu(gate) * val
+// GEGLU, reference src/utils/attention.py:38-41: g = gelu(gate) * val.  The reference stores h as [val | gate] halves of
+// width I; the fused feed-forward keeps them interleaved in blocks of `blk` columns ([val blk | gate blk | val blk | ...])
+// so that a GEMM output tile holds matching value and gate columns.  blk = I is the reference layout.
+// Output column j (chunks of 8, c = j/8): value column = (c / B8) * 2*B8 + c % B8 (in chunks), gate = value + B8.
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ g, long rows,
-                                                        int I8, long ldh, long ldg) {
+                                                        int I8, int B8, long ldh, long ldg) {
   const long total = rows * I8;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / I8;
     const int c = (int)(i % I8);
+    const int vc = (c / B8) * 2 * B8 + c % B8;
     float v[8], t[8], o[8];
-    unpack8(*(const uint4*)(h + r * ldh + c * 8), v);
-    unpack8(*(const uint4*)(h + r * ldh + (long)I8 * 8 + c * 8), t);
+    unpack8(*(const uint4*)(h + r * ldh + vc * 8), v);
+    unpack8(*(const uint4*)(h + r * ldh + (long)(vc + B8) * 8), t);
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = gelu_f(t[k]) * v[k];
     *(uint4*)(g + r * ldg + c * 8) = pack8(o);
@@ -48,22 +53,24 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* __restrict
 }
 
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ dg, const bf16_t* __restrict__ h,
-                                                        bf16_t* __restrict__ dh, long rows, int I8, long lddg, long ldh) {
+                                                        bf16_t* __restrict__ dh, long rows, int I8, int B8, long lddg,
+                                                        long ldh) {
   const long total = rows * I8;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / I8;
     const int c = (int)(i % I8);
+    const int vc = (c / B8) * 2 * B8 + c % B8;
     float v[8], t[8], d[8], dv[8], dt[8];
-    unpack8(*(const uint4*)(h + r * ldh + c * 8), v);
-    unpack8(*(const uint4*)(h + r * ldh + (long)I8 * 8 + c * 8), t);
+    unpack8(*(const uint4*)(h + r * ldh + vc * 8), v);
+    unpack8(*(const uint4*)(h + r * ldh + (long)(vc + B8) * 8), t);
     unpack8(*(const uint4*)(dg + r * lddg + c * 8), d);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       dv[k] = d[k] * gelu_f(t[k]);
       dt[k] = d[k] * v[k] * gelu_grad_f(t[k]);
     }
-    *(uint4*)(dh + r * ldh + c * 8) = pack8(dv);
-    *(uint4*)(dh + r * ldh + (long)I8 * 8 + c * 8) = pack8(dt);
+    *(uint4*)(dh + r * ldh + vc * 8) = pack8(dv);
+    *(uint4*)(dh + r * ldh + (long)(vc + B8) * 8) = pack8(dt);
   }
 }
 
@@ -177,19 +184,20 @@ int ctclip_cast_f32_bf16(const float* x, void* y, long n, void* stream) {
   CTCLIP_CHECK_LAUNCH();
 }
 
-int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, long ldh, long ldg, void* stream) {
+int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, int block, long ldh, long ldg, void* stream) {
   if (rows <= 0) return 0;
-  if ((inner & 7) || (ldh & 7) || (ldg & 7)) return (int)hipErrorInvalidValue;
+  if ((inner & 7) || (ldh & 7) || (ldg & 7) || block <= 0 || (block & 7) || (inner % block)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(rows * (inner / 8))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)h, (bf16_t*)g, rows, inner / 8, ldh, ldg);
+                     (const bf16_t*)h, (bf16_t*)g, rows, inner / 8, block / 8, ldh, ldg);
   CTCLIP_CHECK_LAUNCH();
 }
 
-int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, long lddg, long ldh, void* stream) {
+int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, int block, long lddg, long ldh,
+                     void* stream) {
   if (rows <= 0) return 0;
-  if ((inner & 7) || (ldh & 7) || (lddg & 7)) return (int)hipErrorInvalidValue;
+  if ((inner & 7) || (ldh & 7) || (lddg & 7) || block <= 0 || (block & 7) || (inner % block)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(rows * (inner / 8))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)dg, (const bf16_t*)h, (bf16_t*)dh, rows, inner / 8, lddg, ldh);
+                     (const bf16_t*)dg, (const bf16_t*)h, (bf16_t*)dh, rows, inner / 8, block / 8, lddg, ldh);
   CTCLIP_CHECK_LAUNCH();
 }
 

@@ -92,7 +92,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int rbase, int s, 
   }
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf_fast(x); }
 
 template <bool AKM, bool BKM, int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
@@ -422,7 +422,9 @@ int ctclip_gemm2_launch(const void* A, const void* B, void* C, const float* bias
                         long lda, long ldb, long ldc, long ldr, int a_kmajor, int b_kmajor, int c_fp32, int split_k,
                         int accumulate, float alpha, int act, hipStream_t st);
 int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
-                        long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, hipStream_t st);
+                        long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
+                        hipStream_t st);
+extern "C" int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, int block, long ldh, long ldg, void* stream);
 
 extern "C" {
 
@@ -449,7 +451,8 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
     const long blocks3 = (long)((M + 255) / 256) * ((N + 255) / 256);
     if (!no_v3 && !force_v1 && a_kmajor && b_kmajor && (K % 32) == 0 && split_k <= 1 && !accumulate &&
         (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
-      return ctclip_gemm3_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, (hipStream_t)stream);
+      return ctclip_gemm3_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, nullptr, 0,
+                                 (hipStream_t)stream);
     const long blocks2 = (long)((M + 255) / 256) * ((N + 127) / 128) * (split_k > 1 ? split_k : 1);
     const bool eligible = !force_v1 && (K % 64) == 0 && blocks2 >= 192;
     if (eligible || (v2_all && !force_v1 && (K % 64) == 0 && blocks2 >= 8))
@@ -495,6 +498,22 @@ int ctclip_gemm_argmax_partial(const void* A, const void* B, float* part_val, in
   g.split_k = 1; g.ktiles_per_split = (K + BKT - 1) / BKT; g.alpha = 1.f;
   g.part_val = part_val; g.part_idx = part_idx; g.n_parts = 2 * g.tiles_m;
   return launch<1>(g, 1, 1, (hipStream_t)stream);
+}
+
+int ctclip_gemm_bf16_geglu(const void* A, const void* Bw, void* H, void* G, int M, int inner, int K, long lda, long ldb,
+                           long ldh, long ldg, void* stream) {
+  if (M <= 0 || inner <= 0) return 0;
+  if ((inner & 63) || K <= 0) return (int)hipErrorInvalidValue;
+  const int N = 2 * inner;
+  static const bool no_v3 = getenv("CTCLIP_GEMM_NO_V3") != nullptr;
+  static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
+  const long blocks3 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  const bool aligned = (ldh & 7) == 0 && (ldg & 7) == 0 && ((((uintptr_t)H) | ((uintptr_t)G)) & 15) == 0;
+  if (!no_v3 && aligned && (K % 32) == 0 && (N % 256) == 0 && (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
+    return ctclip_gemm3_launch(A, Bw, H, nullptr, nullptr, M, N, K, lda, ldb, ldh, 0, 0, 1.0f, 2, G, ldg, (hipStream_t)stream);
+  // small problems: the plain product, then the gated activation over the same interleaved layout
+  if (int e = ctclip_gemm_bf16(A, Bw, H, nullptr, nullptr, M, N, K, lda, ldb, ldh, 0, 1, 1, 0, 1, 0, 1.0f, 0, stream)) return e;
+  return ctclip_geglu_fwd(H, G, M, inner, 64, ldh, ldg, stream);
 }
 
 }  // extern "C"

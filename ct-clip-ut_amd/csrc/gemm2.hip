@@ -87,7 +87,7 @@ __device__ __forceinline__ long piece_src(int p, int lane, int r0, int R, long l
   }
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf_fast(x); }
 
 #define G2_GLDS(gptr, ldsoff)                                                                                     \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                          \

@@ -25,6 +25,7 @@ struct Args {
   long lda, ldb, ldc, ldr;
   int M, N, K, tiles_m, tiles_n, c_fp32, act;
   float alpha;
+  bf16_t* G; long ldg;                             // act == 2: gelu(gate) * value of the 64-column interleaved [val|gate] blocks
 };
 
 // [256 rows][32 k] bf16 tile, 64-byte rows, 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128 phase
@@ -45,7 +46,7 @@ __device__ __forceinline__ long piece_src(int p, int lane, int r0, int R, long l
   return (long)row * ld + c * 8;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf_fast(x); }
 
 #define G3_GLDS(gptr, ldsoff)                                                                                     \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                          \
@@ -200,6 +201,16 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
           uint4 o;
           o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
           *(uint4*)(C + (long)row * g.ldc + col) = o;
+          if (act == 2 && ((c8 >> 6) & 1) == 0) {  // a value chunk: its gate sits 64 columns to the right in the same tile
+            const float4 g0 = *(const float4*)(ct + r * BN + c8 + 64), g1 = *(const float4*)(ct + r * BN + c8 + 68);
+            const float gt[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            float w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = gelu_erf(gt[e] * g.alpha) * v[e];
+            uint4 og;
+            og.x = pack_bf16x2(w[0], w[1]); og.y = pack_bf16x2(w[2], w[3]); og.z = pack_bf16x2(w[4], w[5]); og.w = pack_bf16x2(w[6], w[7]);
+            *(uint4*)(g.G + (long)row * g.ldg + (col >> 7) * 64 + (col & 63)) = og;
+          }
         } else {
           for (int e = 0; e < 8 && col + e < g.N; ++e) {
             float x = v[e] + (g.bias ? g.bias[col + e] : 0.f);
@@ -217,8 +228,12 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
 
 // called by ctclip_gemm_bf16 (gemm.hip): k-major x k-major, K % 32 == 0, plain (non-accumulating) output
 int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
-                        long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, hipStream_t st) {
+                        long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
+                        hipStream_t st) {
   using namespace g3;
+  if ((act & 0xff) == 2 && (c_fp32 || bias || resid || !G || (N & 127) || (ldc & 7) || (ldg & 7) || (((uintptr_t)C) & 15) ||
+                            (((uintptr_t)G) & 15)))
+    return (int)hipErrorInvalidValue;
   // 256 x 256 (one workgroup per CU, 4 stages) is the default: equal to the 256 x 128 / two-workgroup form at K = 512 and
   // 5-10 % ahead at K >= 1408 (profiles/r01_gemm_v3.txt).  CTCLIP_GEMM3_BN=128 selects the latter.
   static const int variant = [] {
@@ -230,7 +245,7 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + bn - 1) / bn;
-  g.c_fp32 = c_fp32; g.act = act; g.alpha = alpha;
+  g.c_fp32 = c_fp32; g.act = act; g.alpha = alpha; g.G = (bf16_t*)G; g.ldg = ldg;
   if (bn == 256) {
     const size_t lds = (size_t)4 * (SUB + 256 * BK * 2);   // 128 KiB
     static bool attr_set = false;

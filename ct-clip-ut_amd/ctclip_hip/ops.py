@@ -388,9 +388,9 @@ class FeedForwardFn(Function):
         M = x2.shape[0]
         I, Ip = sh["inner"], sh["inner_p"]
         n2, _, mean, rstd = layernorm(x2, ln_w.detach(), ln_b.detach(), 1e-5)
-        h = gemm(n2, sh["w1"], M, 2 * Ip, dim)
+        h = torch.empty(M, 2 * Ip, dtype=BF16, device=x.device)    # [val 64 | gate 64 | ...] blocks, kept for the backward
         g = torch.empty(M, Ip, dtype=BF16, device=x.device)
-        hip.geglu_fwd(h, g, M, Ip, 2 * Ip, Ip)
+        hip.gemm_bf16_geglu(n2, sh["w1"], h, g, M, Ip, dim, n2.stride(0), sh["w1"].stride(0), 2 * Ip, Ip)
         y = gemm(g, sh["w2"], M, dim, Ip, out_dtype=F32, resid=x2 if residual else None)
         ctx.save_for_backward(x2, ln_w, mean, rstd, n2, h, g)
         ctx.sh, ctx.residual = sh, residual
@@ -413,13 +413,13 @@ class FeedForwardFn(Function):
         dg = dgrad(dyb, sh["w2"], M, dim, Ip, out_dtype=BF16, wT16=sh.get("w2T"))
         wgrad(dyb, g, dim, I, M, out=gw2)                          # g's zero pad columns I..Ip-1 are simply not produced
         dh = torch.empty_like(h)
-        hip.geglu_bwd(dg, h, dh, M, Ip, Ip, 2 * Ip)
+        hip.geglu_bwd(dg, h, dh, M, Ip, 64, Ip, 2 * Ip)
         dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim, out_dtype=BF16, wT16=sh.get("w1T"))
         # one product over all 2*Ip columns of dh (the pad columns are zero): n2 is streamed once and 2*Ip = 2816 is a
         # whole number of 256-row tiles, where two I = 1365-row products each round up to six
-        gw1p = wgrad(dh, n2, 2 * Ip, dim, M)
-        gw1[:I] += gw1p[:I]                                        # value half  (rows 0..I-1 of the reference weight)
-        gw1[I:] += gw1p[Ip:Ip + I]                                 # gate half   (rows I..2I-1)
+        gw1p = wgrad(dh, n2, 2 * Ip, dim, M).view(Ip // 64, 2, 64, dim)   # rows in the interleaved [val 64 | gate 64] order
+        gw1[:I] += gw1p[:, 0].reshape(Ip, dim)[:I]                 # value half  (rows 0..I-1 of the reference weight)
+        gw1[I:] += gw1p[:, 1].reshape(Ip, dim)[:I]                 # gate half   (rows I..2I-1)
         dx = torch.empty(M, dim, dtype=F32, device=dy.device)
         dx16 = torch.empty(M, dim, dtype=BF16, device=dy.device)
         hip.layernorm_bwd_bf16(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, None, dx, dx16, glw, glb, M, dim)

@@ -76,9 +76,15 @@ class FeedForward(nn.Sequential):
         I, Ip = self.inner, ops.pad64(self.inner)      # 1365 -> 1408: every K of the MLP is a whole number of 64-wide k-tiles
 
         def build():
-            w1p = torch.zeros(2 * Ip, self.dim, dtype=BF16, device=w1.device)
-            w1p[:I] = w1[:I]
-            w1p[Ip:Ip + I] = w1[I:]
+            # value rows 0..I-1 and gate rows I..2I-1 of the reference weight, each zero-padded to Ip and then interleaved
+            # in 64-row blocks [val 64 | gate 64 | val 64 | ...]: a 128/256-column GEMM tile then holds matching value and
+            # gate columns and the GEGLU is applied in the GEMM epilogue (ctclip_gemm_bf16_geglu)
+            val = torch.zeros(Ip, self.dim, dtype=BF16, device=w1.device)
+            gate = torch.zeros(Ip, self.dim, dtype=BF16, device=w1.device)
+            val[:I] = w1[:I]
+            gate[:I] = w1[I:]
+            w1p = torch.stack((val.view(Ip // 64, 64, self.dim), gate.view(Ip // 64, 64, self.dim)), dim=1).reshape(2 * Ip, self.dim)
+            w1p = w1p.contiguous()
             w2p = torch.zeros(self.dim, Ip, dtype=BF16, device=w2.device)
             w2p[:, :I] = w2
             return {"w1": w1p, "w2": w2p, "w1T": w1p.t().contiguous(), "w2T": w2p.t().contiguous(), "inner": I, "inner_p": Ip}

@@ -86,9 +86,16 @@ int ctclip_attn_probs(const void* q, const void* k, const float* lse, const floa
 
 /* ---- elementwise ------------------------------------------------------------------------------- */
 int ctclip_cast_f32_bf16(const float* x, void* y, long n, void* stream);
-/* GEGLU attention.py:38-41: h = [val | gate], g = gelu(gate) * val */
-int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, long ldh, long ldg, void* stream);
-int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, long lddg, long ldh, void* stream);
+/* GEGLU attention.py:38-41: g = gelu(gate) * val.  h holds value and gate columns interleaved in blocks of `block`
+ * columns ([val block | gate block | val block | ...]); block = inner is the reference's [val | gate] halves. */
+int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, int block, long ldh, long ldg, void* stream);
+int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, int block, long lddg, long ldh,
+                     void* stream);
+/* Linear(dim, 2*inner, no bias) + GEGLU in one pass (attention.py:38-50): H[M, 2*inner] = A[M,K] Bw[2*inner,K]^T with the
+ * rows of Bw interleaved in 64-row value / gate blocks, and G[M, inner] = gelu(gate) * value written by the same
+ * epilogue (H is still needed by the backward).  inner % 64 == 0, K % 8 == 0. */
+int ctclip_gemm_bf16_geglu(const void* A, const void* Bw, void* H, void* G, int M, int inner, int K, long lda, long ldb,
+                           long ldh, long ldg, void* stream);
 int ctclip_gelu_fwd(const void* h, void* m, long n, void* stream);
 int ctclip_gelu_bwd(const void* dm, const void* h, void* dh, long n, void* stream);
 /* out[b,c,a,:] = in[b,a,c,:] : the spatial<->temporal token re-orderings of ctvit.py:94-101 */

@@ -87,6 +87,33 @@ def test_gemm_pipelined_variant(hip, akm, bkm, M, N, K, split):
     check(f"gemm2 bf16 gelu ({akm},{bkm})", C16, torch.nn.functional.gelu(ref), 1e-2)
 
 
+@pytest.mark.parametrize("M,inner,K", [(3000, 384, 96), (2100, 128, 64), (70, 64, 40)])
+def test_linear_geglu_fused_and_blocked_backward(hip, M, inner, K):
+    """ctclip_gemm_bf16_geglu (reference attention.py:38-50): interleaved [val 64 | gate 64] weight rows, H and
+    G = gelu(gate) * value from one pass (fused epilogue for the first two shapes, product + blocked GEGLU for the last),
+    and the blocked GEGLU backward."""
+    x = bf(rnd(M, K, seed=70))
+    w = bf(rnd(2 * inner, K, seed=71) * 0.2)                              # reference layout: value rows then gate rows
+    wi = torch.stack((w[:inner].view(inner // 64, 64, K), w[inner:].view(inner // 64, 64, K)), 1).reshape(2 * inner, K).contiguous()
+    href = x.float() @ w.float().t()
+    val, gate = href[:, :inner].clone().requires_grad_(True), href[:, inner:].clone().requires_grad_(True)
+    gref = torch.nn.functional.gelu(gate) * val
+    H = torch.empty(M, 2 * inner, device=DEV, dtype=torch.bfloat16)
+    G = torch.empty(M, inner, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16_geglu(x, wi, H, G, M, inner, K, K, K, 2 * inner, inner)
+    Hb = H.float().view(M, inner // 64, 2, 64)
+    check("fused h value", Hb[:, :, 0].reshape(M, inner), href[:, :inner], 1e-2)
+    check("fused h gate", Hb[:, :, 1].reshape(M, inner), href[:, inner:], 1e-2)
+    check("fused g", G, gref, 1.5e-2)
+    dg = bf(rnd(M, inner, seed=72))
+    gref.backward(dg.float())
+    dH = torch.empty_like(H)
+    hip.geglu_bwd(dg, H, dH, M, inner, 64, inner, 2 * inner)
+    dHb = dH.float().view(M, inner // 64, 2, 64)
+    check("blocked geglu dval", dHb[:, :, 0].reshape(M, inner), val.grad, 2e-2)
+    check("blocked geglu dgate", dHb[:, :, 1].reshape(M, inner), gate.grad, 2e-2)
+
+
 def test_gemm_mfma_orientation_asymmetric(hip):
     """A = I with an asymmetric B catches a transposed C write (guide: 'always A=I-check')."""
     n = 128
@@ -354,12 +381,12 @@ def test_elementwise(hip):
     val, gate = h.float()[:, :I].clone().requires_grad_(True), h.float()[:, I:].clone().requires_grad_(True)
     ref = torch.nn.functional.gelu(gate) * val
     g = torch.empty(rows, I, device=DEV, dtype=torch.bfloat16)
-    hip.geglu_fwd(h, g, rows, I, 2 * I, I)
+    hip.geglu_fwd(h, g, rows, I, I, 2 * I, I)
     check("geglu", g, ref, 1e-2)
     dg = bf(rnd(rows, I, seed=31))
     ref.backward(dg.float())
     dh = torch.empty_like(h)
-    hip.geglu_bwd(dg, h, dh, rows, I, I, 2 * I)
+    hip.geglu_bwd(dg, h, dh, rows, I, I, I, 2 * I)
     check("geglu dval", dh[:, :I], val.grad, 1e-2)
     check("geglu dgate", dh[:, I:], gate.grad, 1e-2)
 
