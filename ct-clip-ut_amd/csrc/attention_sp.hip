@@ -175,32 +175,13 @@ __global__ __launch_bounds__(512) void sp_fwd_kernel(SpArgs p) {
     if (w < 2) *(u32x4*)(qbuf + buf * 2048 + img_off<32>(tid >> 2, tid & 3)) = qreg;
   };
 
-  // L2 warm-up two sequences ahead: one dword per 64-byte row piece this wave will load next-but-one iteration.  The
-  // loads of the next sequence then hit L2 instead of paying the HBM latency inside one iteration.  The touched dwords
-  // stay outstanding across the end-of-iteration wait (they are issued after the real loads) and are retired a whole
-  // iteration later.
-  const int nrows = 32 * ntw;
-  const int trow0 = lane < nrows ? lane : nrows - 1, trow1 = 64 + r < nrows ? 64 + r : nrows - 1;
-  const uint32_t tk0 = (uint32_t)((32 * t0 + trow0) * a.ldk + head * 32), tk1 = (uint32_t)((32 * t0 + trow1) * a.ldk + head * 32);
-  const uint32_t tv0 = (uint32_t)((32 * t0 + trow0) * a.ldv + head * 32), tv1 = (uint32_t)((32 * t0 + trow1) * a.ldv + head * 32);
-  uint32_t tch[4] = {0u, 0u, 0u, 0u}, tch_prev[4] = {0u, 0u, 0u, 0u};
-  auto touch = [&](long seq) {
-    const bf16_t* kb = a.k + seq * kseq;
-    const bf16_t* vb = a.v + seq * vseq;
-    tch[0] = *(const uint32_t*)(kb + tk0);
-    tch[1] = *(const uint32_t*)(kb + tk1);
-    tch[2] = *(const uint32_t*)(vb + tv0);
-    tch[3] = *(const uint32_t*)(vb + tv1);
-  };
-
   ld_all(seq0);
   st_staged(0);
   __syncthreads();
 
   for (int seq = seq0; seq < seq1; ++seq) {
     const int buf = (seq - seq0) & 1;
-    const long sn = p.dbg == 1 ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);   // next sequence (the last re-loads its own)
-    const long sn2 = p.dbg == 1 ? seq0 : (seq + 2 < seq1 ? seq + 2 : seq1 - 1);
+    const long sn = (p.dbg & 1) ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);   // next sequence (the last re-loads its own)
     const bf16x8 qf0 = row_frag<32>(qbuf + buf * 2048, 0, 0, lane), qf1 = row_frag<32>(qbuf + buf * 2048, 0, 1, lane);
     f32x16 S[TPW];
 #pragma unroll
@@ -212,9 +193,6 @@ __global__ __launch_bounds__(512) void sp_fwd_kernel(SpArgs p) {
     // every global load of the next sequence is issued here and consumed at the end of this iteration, so no load is
     // in flight across the loop edge (vmcnt is in-order and also counts the combine's stores)
     ld_all(sn);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tch_prev[j] = tch[j];
-    if (p.dbg != 2) touch(sn2);
     float m = -INFINITY;
 #pragma unroll
     for (int u = 0; u < TPW; ++u)
@@ -257,12 +235,15 @@ __global__ __launch_bounds__(512) void sp_fwd_kernel(SpArgs p) {
       mbuf[w * 64 + 32 + r] = l;
     }
     st_staged(buf ^ 1);                                  // own V rows (own transposed reads are done) + the next Q block
-    asm volatile("" ::"v"(tch_prev[0]), "v"(tch_prev[1]), "v"(tch_prev[2]), "v"(tch_prev[3]));
-    lds_barrier();
+    // the K fragments of the next sequence are consumed here too (a register use the compiler waits for): nothing loaded
+    // is then in flight across the loop edge, where the only vmcnt wait it could place would also cover the combine's stores
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) asm volatile("" : "+v"(kf[u][0]), "+v"(kf[u][1]));
+    if (!(p.dbg & 4)) lds_barrier();
     // combine the W partial rows: O = sum_w 2^(m_w - m) O_w / sum_w 2^(m_w - m) l_w.  Done by the LAST four waves: when
     // the tiles do not divide evenly the first waves carry the extra tile.
-    const int idx = tid - (nthreads - 256);
-    if (idx >= 0) {
+    const int idx = (p.W == 8) ? (((w & 2) ? (((w >> 2) << 1) | (w & 1)) : -1) * 64 + lane) : tid - (nthreads - 256);
+    if (idx >= 0 && !(p.dbg & 8)) {
       const int cl = idx & 63, rg = idx >> 6, q = cl & 31, ch = cl >> 5;
       float mw[kMaxWaves], lw[kMaxWaves];
       float4 tw[kMaxWaves];
@@ -403,7 +384,7 @@ __global__ __launch_bounds__(512) void sp_bwd_dq_kernel(SpArgs p) {
 
   for (int seq = seq0; seq < seq1; ++seq) {
     const int buf = (seq - seq0) & 1;
-    const long sn = p.dbg == 1 ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);
+    const long sn = (p.dbg & 1) ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);
     const char* qdb = qd + buf * 4096;
     const bf16x8 qf0 = row_frag<32>(qdb, 0, 0, lane), qf1 = row_frag<32>(qdb, 0, 1, lane);
     const bf16x8 df0 = row_frag<32>(qdb + 2048, 0, 0, lane), df1 = row_frag<32>(qdb + 2048, 0, 1, lane);
@@ -579,7 +560,7 @@ __global__ __launch_bounds__(512) void sp_bwd_dkv_kernel(SpArgs p) {
 
   for (int seq = seq0; seq < seq1; ++seq) {
     const int buf = (seq - seq0) & 1;
-    const long sn = p.dbg == 1 ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);
+    const long sn = (p.dbg & 1) ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);
     const char* kvb = kvbuf + buf * 4096;
     const bf16x8 kf0 = row_frag<32>(kvb, 0, 0, lane), kf1 = row_frag<32>(kvb, 0, 1, lane);
     const bf16x8 vf0 = row_frag<32>(kvb + 2048, 0, 0, lane), vf1 = row_frag<32>(kvb + 2048, 0, 1, lane);
