@@ -97,6 +97,7 @@ class CTClipTrainer(nn.Module):
 
         self.metrics, self.train_losses, self.valid_losses = [], {}, []
         self.best_score = float("inf")
+        self.global_step = 0
         self.results_folder = None
         if self.accelerator.process_index == 0 and results_folder:
             root = Path(results_folder) / datetime.now().strftime("%d-%m-%Y")
@@ -108,7 +109,11 @@ class CTClipTrainer(nn.Module):
     # ---- checkpoints (reference :136-154) ---------------------------------------------------------------------
     def save_model(self, name, log=None):
         if self.accelerator.is_main_process and self.results_folder is not None:
-            pkg = {"model": self.model.state_dict(), "optim": self.optim.state_dict()}
+            # "model" / "optim" as in the reference (:140-143); the rest is what a real resume needs and the reference
+            # drops: global step, loss history, RNG streams
+            pkg = {"model": self.model.state_dict(), "optim": self.optim.state_dict(), "step": self.global_step,
+                   "train_losses": self.train_losses, "valid_losses": self.valid_losses, "best_score": self.best_score,
+                   "rng": {"torch": torch.get_rng_state(), "cuda": torch.cuda.get_rng_state(self.accelerator.device)}}
             torch.save(pkg, str(self.results_folder / name))
             with open(self.results_folder / "architecture.txt", "w") as f:
                 f.write(str(self.model))
@@ -119,10 +124,17 @@ class CTClipTrainer(nn.Module):
         path = Path(path)
         if not path.exists():
             raise FileNotFoundError(f"Checkpoint not found at {path}")
-        pkg = torch.load(path, map_location=self.accelerator.device)
+        pkg = torch.load(path, map_location=self.accelerator.device, weights_only=False)
         self.model.load_state_dict(pkg["model"])
         self.optim.load_state_dict(pkg["optim"])
         ops.bump_weight_epoch()
+        self.global_step = int(pkg.get("step", 0))
+        self.train_losses = pkg.get("train_losses", self.train_losses)
+        self.valid_losses = pkg.get("valid_losses", self.valid_losses)
+        self.best_score = pkg.get("best_score", self.best_score)
+        if "rng" in pkg:
+            torch.set_rng_state(pkg["rng"]["torch"].cpu())
+            torch.cuda.set_rng_state(pkg["rng"]["cuda"].cpu(), self.accelerator.device)
 
     # ---- loss bookkeeping (reference :156-175) -----------------------------------------------------------------
     def avg_device_loss(self, loss):
@@ -160,6 +172,7 @@ class CTClipTrainer(nn.Module):
         loss.backward()
         self.grad_sync.all_reduce_grads()
         self.optim.step(max_grad_norm=self.max_grad_norm if self.max_grad_norm else None)
+        self.global_step += 1
         return loss.detach() if return_tensor else loss.item()
 
     @torch.no_grad()

@@ -345,11 +345,15 @@ def symmetric_info_nce(sim: Tensor, targets: Optional[Tensor] = None) -> Tensor:
 
 
 def ctclip_forward(text_inputs: Mapping[str, Tensor], volume: Tensor, st: State, cfg: dict,
-                   training: bool = False):
-    """Single-process CTCLIP.forward (ctclip.py:99-129). Returns dict of everything."""
-    cls = bert_cls(text_inputs["input_ids"], text_inputs.get("token_type_ids"),
-                   text_inputs.get("attention_mask"), st, "text_transformer.",
-                   cfg["text_layers"], cfg["text_heads"])
+                   training: bool = False, text_embeds: Tensor = None):
+    """Single-process CTCLIP.forward (ctclip.py:99-129). Returns dict of everything.
+    `text_embeds` replaces the text encoder's CLS output when text_inputs is None/empty (ctclip.py:107)."""
+    if text_inputs:
+        cls = bert_cls(text_inputs["input_ids"], text_inputs.get("token_type_ids"),
+                       text_inputs.get("attention_mask"), st, "text_transformer.",
+                       cfg["text_layers"], cfg["text_heads"])
+    else:
+        cls = text_embeds
     tokens, idx, ncs, nemb = ctvit_forward(volume, st, "visual_transformer.", cfg, training)
     tl, il = clip_latents(cls, tokens, st)
     sim = sim_matrix(il, tl, st["temperature"])
@@ -418,3 +422,48 @@ def train_steps(st0: Dict[str, Tensor], batches, cfg: dict, lr: float = 1.25e-5,
         losses.append(float(loss.detach()))
         norms.append(total)
     return losses, norms, {k: v.detach() for k, v in st.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# occlusion sensitivity, restated from reference src/utils/visualizations.py:335-424
+# (`Visualizations._compute_occlusion`): serial B=1 forwards, one per voxel window.
+# ---------------------------------------------------------------------------------------------------------------------
+def occlusion_heatmap(text_inputs, image, st, cfg, patch_size, stride, threshold=0.0, text_embeds=None, rank=0, world_size=1):
+    """visualizations.py:335-424 for one process (rank / world_size select the window slice exactly as :352-362).
+
+    image [1,1,D,H,W]; returns the rank's UN-reduced (heatmap, count_map) and, for world_size == 1, the final map
+    (normalised, thresholded, rot90) the reference returns on the main process."""
+    import numpy as np
+    _, _, D, H, W = image.shape
+    coords = [(d, h, w)
+              for d in range(0, D - patch_size[0] + 1, stride[0])
+              for h in range(0, H - patch_size[1] + 1, stride[1])
+              for w in range(0, W - patch_size[2] + 1, stride[2])]
+    per_rank = len(coords) // world_size                                   # :352-353 (extra windows are dropped, :356)
+    coords = coords[:per_rank * world_size][rank * per_rank:(rank + 1) * per_rank]
+    heat = torch.zeros(D, H, W, dtype=torch.float64)
+    count = torch.zeros(D, H, W, dtype=torch.float64)
+
+    def score(img):
+        with torch.no_grad():
+            out = ctclip_forward(text_inputs, img, st, cfg, training=False, text_embeds=text_embeds)
+        return float(out["sim"][0, 0])
+
+    original = score(image)                                                # :370-375
+    for d, h, w in coords:                                                 # :379-391
+        occ = image.clone()
+        occ[:, :, d:d + patch_size[0], h:h + patch_size[1], w:w + patch_size[2]] = -1
+        importance = max(original - score(occ), 0.0)
+        heat[d:d + patch_size[0], h:h + patch_size[1], w:w + patch_size[2]] += importance
+        count[d:d + patch_size[0], h:h + patch_size[1], w:w + patch_size[2]] += 1
+    final = None
+    if world_size == 1:                                                    # :409-424
+        c = count.clone()
+        c[c == 0] = 1
+        hm = (heat / c).float()
+        hm = (hm - hm.min()) / (hm.max() - hm.min() + 1e-8)
+        hm = torch.nn.functional.interpolate(hm[None, None], size=(D, H, W), mode="trilinear", align_corners=False)[0, 0]
+        hm = hm.numpy().copy()
+        hm[hm < threshold] = 0
+        final = np.rot90(hm, k=-1, axes=(1, 2))
+    return heat, count, final

@@ -306,3 +306,78 @@ def test_config1_two_training_steps():
               f"grad-norm {trainer.optim.grad_norm():.4f} / {ref_norms[s]:.4f}")
         assert math.isfinite(loss) and rel <= 5e-2      # free-running codes on a 64-token toy: see test_config1_vs_oracle
         assert abs(trainer.optim.grad_norm() - ref_norms[s]) <= 0.15 * ref_norms[s]
+
+
+# ------------------------------------------------------------------------------------------- SURVEY 8(f) row f1
+def test_batched_occlusion_sensitivity_vs_serial_and_oracle():
+    """utils.visualizations.Visualizations._compute_occlusion (reference src/utils/visualizations.py:335-424): windows
+    scored in device-side batches with the text side encoded once must give the heat-map of the reference's serial
+    one-forward-per-window loop -- (a) against the same HIP model run with batch 1, (b) against the f32 oracle restatement
+    of the reference loop."""
+    import numpy as np
+    from oracle import ctclip_oracle as O
+    from utils.visualizations import Visualizations
+
+    class Acc:                                     # the attributes of accelerate.Accelerator the class reads
+        is_main_process, process_index, num_processes, device = True, 0, 1, torch.device(DEV)
+
+    clip, data, cfg = _config1()
+    st = {k: v.clone() for k, v in clip.state_dict().items()}
+    txt, vol = data[0]
+    txt1 = {k: v[:1] for k, v in txt.items()}
+    image = vol[:1]
+    patch, stride = (32, 32, 32), (32, 32, 16)     # 2 x 2 x 3 = 12 windows, overlapping along w
+    clip = clip.to(DEV)
+    maps = {}
+    for b in (5, 1):                               # 5: two full batches + a ragged one; 1: the serial schedule
+        vis = Visualizations(clip, Acc(), occlusion_batch=b)
+        maps[b] = vis._compute_occlusion(image, txt1, None, patch, stride, 0.0)
+    assert maps[5].shape == (64, 64, 64)
+    check("occlusion batched vs serial (HIP)", torch.from_numpy(maps[5].copy()), torch.from_numpy(maps[1].copy()), 2e-2)
+    _, _, ref = O.occlusion_heatmap(txt1, image, st, cfg, patch, stride, 0.0)
+    a, b_ = maps[5].reshape(-1).astype(np.float64), ref.reshape(-1).astype(np.float64)
+    corr = float(np.corrcoef(a, b_)[0, 1])
+    print(f"  occlusion heat-map vs oracle: correlation {corr:.5f}, max |diff| {np.abs(a - b_).max():.3e}")
+    # free-running comparison: every occluded copy goes through the VQ arg-max, whose genuine near-ties flip under bf16
+    # noise (the caveat of test_config1_vs_oracle), so the maps agree in shape, not to rounding
+    assert corr >= 0.93 and np.abs(a - b_).max() <= 0.3
+    # precomputed text embeddings (the reference's `text_embeds` branch, :371-372,384-385)
+    emb = clip.encode_text({k: v.to(DEV) for k, v in txt1.items()}).detach()
+    m2 = Visualizations(clip, Acc(), occlusion_batch=4)._compute_occlusion(image, None, emb, patch, stride, 0.0)
+    check("occlusion with text_embeds", torch.from_numpy(m2.copy()), torch.from_numpy(maps[5].copy()), 2e-2)
+
+
+# ------------------------------------------------------------------------------------------- SURVEY 8(f) row f3
+def test_checkpoint_resume_continues_the_run(tmp_path):
+    """save_model / load_model (reference src/utils/CTClipTrainer.py:136-154) carry the optimiser moments and -- beyond
+    the reference -- the global step: a trainer restored from the checkpoint takes the same next step as the original."""
+    from utils.CTClipTrainer import CTClipTrainer
+    clip, data, _ = _config1()
+    trainer = CTClipTrainer(clip, batch_size=4, results_folder=str(tmp_path))
+    (txt0, vol0), (txt1, vol1) = data
+    trainer.train_step((vol0, txt0))
+    trainer.save_model("ckpt.pt")
+    ckpt = trainer.results_folder / "ckpt.pt"
+    assert ckpt.exists() and (trainer.results_folder / "architecture.txt").exists()
+    loss_a = trainer.train_step((vol1, txt1))
+    after_a = {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}
+
+    clip_b, _, _ = _config1()                      # fresh model + trainer, then restore
+    with torch.no_grad():
+        for p in clip_b.parameters():
+            p.add_(0.01)                           # make sure the restore is what brings the weights back
+    trainer_b = CTClipTrainer(clip_b, batch_size=4, results_folder=None)
+    trainer_b.load_model(ckpt)
+    assert trainer_b.global_step == 1
+    loss_b = trainer_b.train_step((vol1, txt1))
+    assert trainer_b.global_step == 2
+    print(f"  resumed step: loss {loss_b:.7f} vs uninterrupted {loss_a:.7f}")
+    assert abs(loss_a - loss_b) <= 1e-4 * abs(loss_a)
+    worst = 0.0
+    for k, v in trainer_b.model.state_dict().items():
+        if v.is_floating_point() and v.numel():
+            worst = max(worst, float((v - after_a[k]).abs().max() / (after_a[k].abs().max() + 1e-12)))
+    print(f"  worst parameter deviation after the resumed step: {worst:.2e}")
+    assert worst <= 1e-3                           # f32 atomics reorder sums; Adam's first steps amplify that to ~1e-4
+    with pytest.raises(FileNotFoundError):
+        trainer_b.load_model(tmp_path / "missing.pt")
