@@ -133,3 +133,47 @@ def test_position_table_indexing_matches_dense_grid():
         dense = O.cpb_relpos(h, w)
         assert rows.shape[0] == (2 * h - 1) * (2 * w - 1)
         assert torch.equal(rows[relidx.to(torch.int64)], dense)
+
+
+def test_occlusion_window_slices_partition_the_scan():
+    """reference src/utils/visualizations.py:352-362: ranks take contiguous, equal slices of the window list (extra
+    windows dropped); the reduced rank maps equal the single-process maps (oracle restatement, tiny model)."""
+    from transformers import BertConfig, BertModel
+    from oracle import ctclip_oracle as O
+    torch.manual_seed(0)
+    cfg = dict(dim=32, codebook_size=64, image_size=32, patch_size=16, temporal_patch_size=16, spatial_depth=1,
+               temporal_depth=1, dim_head=8, heads=2, text_layers=1, text_heads=2)
+    from models.ctclip import CTCLIP
+    from utils.ctvit import CTViT
+    vit = CTViT(**{k: v for k, v in cfg.items() if not k.startswith("text_")})
+    bert = BertModel(BertConfig(hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                                vocab_size=50, max_position_embeddings=16, hidden_dropout_prob=0.0,
+                                attention_probs_dropout_prob=0.0))
+    clip = CTCLIP(text_encoder=bert, image_encoder=vit, dim_text=32, dim_image=2 * 2 * 32, dim_latent=16)
+    st = {k: v.clone() for k, v in clip.state_dict().items()}
+    gen = torch.Generator().manual_seed(3)
+    image = (torch.randn(1, 1, 32, 32, 32, generator=gen) * 0.5).clamp(-1, 1)
+    ids = torch.randint(0, 50, (1, 8), generator=gen)
+    txt = {"input_ids": ids, "token_type_ids": torch.zeros_like(ids), "attention_mask": torch.ones_like(ids)}
+    patch, stride = (16, 16, 16), (16, 16, 8)                       # 2 x 2 x 3 = 12 windows
+    h1, c1, final = O.occlusion_heatmap(txt, image, st, cfg, patch, stride)
+    parts = [O.occlusion_heatmap(txt, image, st, cfg, patch, stride, rank=r, world_size=2) for r in range(2)]
+    assert all(p[2] is None for p in parts) and final.shape == (32, 32, 32)
+    torch.testing.assert_close(parts[0][0] + parts[1][0], h1)
+    torch.testing.assert_close(parts[0][1] + parts[1][1], c1)
+    assert float(c1.max()) == 2.0 and float(c1.min()) == 1.0       # stride 8 along w: the middle band is covered twice
+    assert 0.0 <= float(final.min()) and float(final.max()) <= 1.0
+    # 5 ranks: 12 // 5 = 2 windows each, the last two windows are dropped (reference :356)
+    p5 = [O.occlusion_heatmap(txt, image, st, cfg, patch, stride, rank=r, world_size=5) for r in range(5)]
+    assert float(sum(p[1] for p in p5).sum()) == 10 * 16 ** 3
+
+
+def test_visualizations_scope():
+    from utils.visualizations import Visualizations
+
+    class Acc:
+        is_main_process, process_index, num_processes, device = True, 0, 1, torch.device("cpu")
+
+    vis = Visualizations(torch.nn.Linear(2, 2), Acc())
+    with pytest.raises(NotImplementedError):
+        vis.visualize(visualizations=["grad_cam"])
