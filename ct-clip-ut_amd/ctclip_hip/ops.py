@@ -99,13 +99,63 @@ def _splits_for(m_out: int, n_out: int, k: int) -> int:
     return max(1, min(nk, (1024 + tiles - 1) // tiles))
 
 
-def wgrad(dy16, x16, n_feat, k_feat, tokens, out=None):
-    """dW[n_feat,k_feat] (+)= dy^T x over `tokens` rows; f32 atomics (out must be zero or a running sum)."""
-    if out is None:
-        out = torch.zeros(n_feat, k_feat, dtype=F32, device=dy16.device)
+# ---- weight gradients on a second HIP stream -------------------------------------------------------------------------
+# Weight-gradient GEMMs are off the backward's critical path (their results only land in `.grad`) and are matrix-pipe
+# bound, while the kernels that follow them on the main stream (GEGLU / LayerNorm / PEG backward) are HBM bound: issued on
+# a side stream the two kinds share the CUs.  The side stream waits for an event recorded at the issue point (inputs are
+# complete), the operands are pinned for it (`record_stream`), and the main stream re-joins it in a callback queued to
+# the end of the running backward pass, so `.grad` is complete whenever `backward()` returns.  CTCLIP_WGRAD_STREAM=0
+# keeps everything on one stream.
+import os as _os
+
+_side = {"on": _os.environ.get("CTCLIP_WGRAD_STREAM", "1") != "0", "stream": None, "dirty": False, "queued": False}
+
+
+def join_side_stream() -> None:
+    _side["queued"] = False
+    if _side["dirty"]:
+        torch.cuda.current_stream().wait_stream(_side["stream"])
+        _side["dirty"] = False
+
+
+def on_side_stream(fn, *pinned):
+    """Run fn() (kernel launches only) on the weight-gradient stream, ordered after everything issued so far."""
+    if not _side["on"] or not pinned[0].is_cuda:
+        return fn()
+    if _side["stream"] is None:
+        _side["stream"] = torch.cuda.Stream()
+    s = _side["stream"]
+    ev = torch.cuda.current_stream().record_event()
+    with torch.cuda.stream(s):
+        s.wait_event(ev)
+        r = fn()
+    for t in pinned:
+        t.record_stream(s)
+    _side["dirty"] = True
+    if not _side["queued"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
+            _side["queued"] = True
+        except RuntimeError:                     # not inside a backward pass: join right away
+            join_side_stream()
+    return r
+
+
+def _wgrad_now(dy16, x16, n_feat, k_feat, tokens, out):
     hip.gemm_bf16(dy16, x16, out, None, None, n_feat, k_feat, tokens, dy16.stride(0), x16.stride(0), out.stride(0), 0,
                   0, 0, 1, _splits_for(n_feat, k_feat, tokens), 1, 1.0, 0)
     return out
+
+
+def wgrad(dy16, x16, n_feat, k_feat, tokens, out=None):
+    """dW[n_feat,k_feat] (+)= dy^T x over `tokens` rows; f32 atomics (out must be zero or a running sum).
+
+    With `out` given (a `.grad` slot) the product is fire-and-forget on the side stream; without, the caller consumes the
+    result right away and it stays on the current stream."""
+    if out is None:
+        out = torch.zeros(n_feat, k_feat, dtype=F32, device=dy16.device)
+        return _wgrad_now(dy16, x16, n_feat, k_feat, tokens, out)
+    return on_side_stream(lambda: _wgrad_now(dy16, x16, n_feat, k_feat, tokens, out), dy16, x16, out)
 
 def colsum(x2d, out=None):
     """out[c] (+)= sum_r x[r, c]  (bias gradients); x f32 or bf16."""
@@ -417,9 +467,11 @@ class FeedForwardFn(Function):
         dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim, out_dtype=BF16, wT16=sh.get("w1T"))
         # one product over all 2*Ip columns of dh (the pad columns are zero): n2 is streamed once and 2*Ip = 2816 is a
         # whole number of 256-row tiles, where two I = 1365-row products each round up to six
-        gw1p = wgrad(dh, n2, 2 * Ip, dim, M).view(Ip // 64, 2, 64, dim)   # rows in the interleaved [val 64 | gate 64] order
-        gw1[:I] += gw1p[:, 0].reshape(Ip, dim)[:I]                 # value half  (rows 0..I-1 of the reference weight)
-        gw1[I:] += gw1p[:, 1].reshape(Ip, dim)[:I]                 # gate half   (rows I..2I-1)
+        def ff1_wgrad():
+            gw1p = wgrad(dh, n2, 2 * Ip, dim, M).view(Ip // 64, 2, 64, dim)   # rows in the interleaved [val 64 | gate 64] order
+            gw1[:I] += gw1p[:, 0].reshape(Ip, dim)[:I]             # value half  (rows 0..I-1 of the reference weight)
+            gw1[I:] += gw1p[:, 1].reshape(Ip, dim)[:I]             # gate half   (rows I..2I-1)
+        on_side_stream(ff1_wgrad, dh, n2, gw1)
         dx = torch.empty(M, dim, dtype=F32, device=dy.device)
         dx16 = torch.empty(M, dim, dtype=BF16, device=dy.device)
         hip.layernorm_bwd_bf16(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, None, dx, dx16, glw, glb, M, dim)
