@@ -281,6 +281,7 @@ class PegFn(Function):
         hip.peg_fwd(xc, w27, bias.detach(), y, y16, b, t, h, w, d, int(residual))
         ctx.save_for_backward(xc, w27)
         ctx.geom = (b, t, h, w, d, int(residual))
+        ctx.params = (weight, bias)
         ctx.mark_non_differentiable(y16)
         return y, y16
 
@@ -293,6 +294,18 @@ class PegFn(Function):
         dx16 = torch.empty(dyc.shape, dtype=BF16, device=dyc.device)
         hip.peg_bwd_data(dyc, w27, dx, dx16, b, t, h, w, d, residual)
         _tag16(dx, dx16)
+        p_w, p_b = ctx.params
+        gw, dw_direct = grad_slot(p_w)
+        gb, db_direct = grad_slot(p_b)
+        if dw_direct and db_direct:
+            # HBM-bound and off the critical path: on the side stream it shares the chip with the matrix-bound GEMMs of the
+            # layer whose backward comes next; the tap-major result is folded into the [d,1,3,3,3] gradient there too
+            def peg_wgrad():
+                dw27 = torch.zeros(27, d, dtype=F32, device=dy.device)
+                hip.peg_bwd_weight(dyc, xc, dw27, gb, b, t, h, w, d)
+                gw.view(d, 27).add_(dw27.t())
+            on_side_stream(peg_wgrad, dyc, xc, gw, gb)
+            return dx, None, None, None, None
         dw27 = torch.zeros(27, d, dtype=F32, device=dy.device)
         db = torch.zeros(d, dtype=F32, device=dy.device)
         hip.peg_bwd_weight(dyc, xc, dw27, db, b, t, h, w, d)
