@@ -594,11 +594,12 @@ __global__ __launch_bounds__(512) void sp_bwd_dkv_kernel(SpArgs p) {
         dkacc = mfma32(tr_frag<32>(qimg, qrow0, 1, 0, lane), d1, dkacc);
         __builtin_amdgcn_sched_barrier(0);
       }
-    lds_barrier();                                       // the previous sequence's combine has left partk / partv
+    if (!(p.dbg & 16)) lds_barrier();                    // the previous sequence's combine has left partk / partv
     part_store(partk, w, lane, dkacc);
     part_store(partv, w, lane, dvacc);
     st_staged(buf ^ 1);                                  // own Q / dO rows + stats (own reads are done), next K / V block
-    lds_barrier();
+    if (!(p.dbg & 4)) lds_barrier();
+    if (!(p.dbg & 8))
     for (int idx = tid; idx < 512; idx += nthreads) {
       const int which = idx >> 8, cl = idx & 63, rg = (idx >> 6) & 3, key = cl & 31, ch = cl >> 5;
       const float4 acc = part_sum(which ? partv : partk, p.W, cl, rg);

@@ -267,6 +267,60 @@ __global__ __launch_bounds__(PF_THREADS) void patch_ln_bwd_fast(const TIN* __res
   }
 }
 
+// d(volume) of gather + LayerNorm (needed only when the input itself is differentiated: integrated gradients,
+// reference src/utils/visualizations.py:851-910).  Same block decomposition as patch_ln_fwd_kernel; the tubelets are
+// gathered in feature order, dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) with g = dA * gamma is scattered back to
+// the voxel each feature came from (every voxel belongs to exactly one tubelet: plain stores, no atomics).
+template <typename TIN>
+__global__ __launch_bounds__(256) void patch_ln_bwd_dx_kernel(const TIN* __restrict__ vol, const bf16_t* __restrict__ dA, long ldd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* __restrict__ dvol,
+                                                              PatchGeom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TIN* buf = (TIN*)smem;
+  float* sm1 = (float*)(smem + (size_t)g.tpb * g.F * sizeof(TIN));
+  float* sm2 = sm1 + g.tpb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = blockIdx.x;
+  const int wg = bid % g.wgroups; bid /= g.wgroups;
+  const int h = bid % g.Ht; bid /= g.Ht;
+  const int t = bid % g.Tt;
+  const int b = bid / g.Tt;
+  const int w0 = wg * g.tpb;
+  const int ntok = min(g.tpb, g.Wt - w0);
+  gather_block<TIN>(buf, vol, g, b, t, h, w0, ntok, tid);
+  __syncthreads();
+  const long row0 = (((long)b * g.Tt + t) * g.Ht + h) * g.Wt + w0;
+  for (int tok = wave; tok < ntok; tok += 4) {
+    const TIN* r = buf + tok * g.F;
+    const bf16_t* d = dA + (row0 + tok) * ldd;
+    const float mu = mean[row0 + tok], rs = rstd[row0 + tok];
+    float s1 = 0.f, s2 = 0.f;
+    for (int f = lane; f < g.F; f += 64) {
+      const float gg = bf16_to_f32(d[f]) * gamma[f];
+      s1 += gg;
+      s2 += gg * (ldf<TIN>(r[f]) - mu) * rs;
+    }
+    s1 = wave_sum(s1) / (float)g.F;
+    s2 = wave_sum(s2) / (float)g.F;
+    if (lane == 0) { sm1[tok] = s1; sm2[tok] = s2; }
+  }
+  __syncthreads();
+  const int nrows = g.C * g.pt * g.p, rowlen = ntok * g.p;
+  for (int e = tid; e < nrows * rowlen; e += 256) {
+    const int rowid = e / rowlen, col = e - rowid * rowlen;
+    const int c = rowid / (g.pt * g.p), rem = rowid - c * g.pt * g.p;
+    const int pti = rem / g.p, p1i = rem - pti * g.p;
+    const long dst = ((((long)b * g.C + c) * g.Dz + t * g.pt + pti) * g.Hy + h * g.p + p1i) * g.Wx + (long)w0 * g.p + col;
+    const int tok = col / g.p, p2i = col - tok * g.p;
+    const int f = rowid * g.p + p2i;
+    const float mu = mean[row0 + tok], rs = rstd[row0 + tok];
+    const float gg = bf16_to_f32(dA[(row0 + tok) * ldd + f]) * gamma[f];
+    const float xh = (ldf<TIN>(buf[tok * g.F + f]) - mu) * rs;
+    dvol[dst] = rs * (gg - sm1[tok] - xh * sm2[tok]);
+  }
+}
+
 // fast-path eligibility + geometry: tpb must divide Wt and give whole 16-byte vectors per row
 bool fast_geom(PatchGeom& g, const void* vol, size_t esz, size_t* lds) {
   if ((g.p & 1) || (g.F & 7) || (g.F > 4096) || ((uintptr_t)vol & 15) || (((size_t)g.Wx * esz) & 15)) return false;
@@ -373,6 +427,26 @@ int ctclip_patch_ln_bwd(const void* volume, int volume_is_bf16, const void* dA_b
     if (lds > 65536) hipFuncSetAttribute((const void*)patch_ln_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(patch_ln_bwd_kernel<float>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const float*)volume,
                        (const bf16_t*)dA_bf16, ldd, mean, rstd, dgamma, dbeta, g);
+  }
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_patch_ln_bwd_dx(const void* volume, int volume_is_bf16, const void* dA_bf16, long ldd, const float* gamma,
+                           const float* mean, const float* rstd, float* dvolume, int B, int C, int Dz, int Hy, int Wx, int pt,
+                           int p, void* stream) {
+  PatchGeom g{};
+  size_t lds = 0;
+  const long F = (long)C * pt * p * p;
+  if (int e = make_geom(g, B, C, Dz, Hy, Wx, pt, p, (F + 7) / 8 * 8, 0.f, volume_is_bf16, &lds)) return e;
+  const unsigned nblk = (unsigned)((long)B * g.Tt * g.Ht * g.wgroups);
+  if (volume_is_bf16) {
+    if (lds > 65536) hipFuncSetAttribute((const void*)patch_ln_bwd_dx_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(patch_ln_bwd_dx_kernel<bf16_t>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)volume,
+                       (const bf16_t*)dA_bf16, ldd, gamma, mean, rstd, dvolume, g);
+  } else {
+    if (lds > 65536) hipFuncSetAttribute((const void*)patch_ln_bwd_dx_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(patch_ln_bwd_dx_kernel<float>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const float*)volume,
+                       (const bf16_t*)dA_bf16, ldd, gamma, mean, rstd, dvolume, g);
   }
   CTCLIP_CHECK_LAUNCH();
 }

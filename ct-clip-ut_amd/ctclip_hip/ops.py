@@ -584,7 +584,13 @@ class PatchEmbedFn(Function):
         d1w, k5 = grad_slot(p_l1w)
         d1b, k6 = grad_slot(p_l1b)
         hip.patch_ln_bwd(vol, int(vol.dtype == BF16), dA, ldA, mean1, rstd1, d1w, d1b, B, C, Dz, Hy, Wx, tpatch, patch)
-        return None, _ret(d1w, k5), _ret(d1b, k6), _ret(dw, k4), _ret(db, k3), _ret(d2w, k1), _ret(d2b, k2), None, None
+        dvol = None
+        if ctx.needs_input_grad[0]:                    # input attribution only (integrated gradients)
+            dvol = torch.empty(vol.shape, dtype=F32, device=dev)
+            hip.patch_ln_bwd_dx(vol, int(vol.dtype == BF16), dA, ldA, p_l1w.detach(), mean1, rstd1, dvol, B, C, Dz, Hy, Wx,
+                                tpatch, patch)
+            dvol = dvol.to(vol.dtype)
+        return dvol, _ret(d1w, k5), _ret(d1b, k6), _ret(dw, k4), _ret(db, k3), _ret(d2w, k1), _ret(d2b, k2), None, None
 
 
 # ---------------------------------------------------------------------------------------------------

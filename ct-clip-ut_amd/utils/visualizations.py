@@ -15,8 +15,10 @@ updates per window).  Here:
     the maps are reduced to rank 0 with one RCCL reduce each (:404-407).
 Same return value: the normalised, thresholded, rot90'd heat-map on the main process, None elsewhere.
 
-Out of scope here (NotImplementedError): attention maps / rollout, Grad-CAM, integrated gradients (needs d/d(volume) of
-the patch embedding) and the matplotlib overlays."""
+`visualize_integrated_gradients` (:851-910) is here too: the `steps` interpolation points go through batched forward +
+backward passes whose input gradient comes from ctclip_patch_ln_bwd_dx.
+
+Out of scope here (NotImplementedError): attention maps / rollout, Grad-CAM and the matplotlib overlays."""
 from __future__ import annotations
 
 from pathlib import Path
@@ -128,7 +130,58 @@ class Visualizations:
             np.save(out / f"{scan_name}_{str(patch_size)}_{str(stride)}_{prompt}_heatmaps.npy", heatmaps)
         return heatmaps
 
+    # ---- reference :851-910 ----------------------------------------------------------------------------------
+    def _integrated_gradients(self, image, text_tokens, steps=50, text_embeds=None, ig_batch=10):
+        """Average d sim / d volume over `steps` points of the straight path from the all-ones baseline to the image
+        (reference :852-878).  The reference runs `steps` B=1 forward+backward passes and re-encodes the report each time;
+        here the text side is encoded once and `ig_batch` interpolation points go through one batched forward + backward
+        (the samples of a batch are independent, so d(sum_i sim[i,0]) / d(x_i) is each point's own gradient).
+        Needs d(volume) of the tubelet embedding: ctclip_patch_ln_bwd_dx."""
+        dev = self.accelerator.device
+        model = self.model
+        image = image.to(dev).float()
+        baseline = torch.ones_like(image)
+        diff = image - baseline
+        was_training, gathered = model.training, model.gather_negatives
+        model.eval()
+        model.gather_negatives = False
+        try:
+            with torch.no_grad():
+                if isinstance(text_embeds, torch.Tensor) and text_embeds.ndim > 1:
+                    cls = text_embeds.to(dev)[:1]
+                else:
+                    cls = model.encode_text({k: v.to(dev) for k, v in text_tokens.items()})[:1]
+            alphas = torch.linspace(0, 1, steps, device=dev)
+            total = torch.zeros_like(image)
+            for i0 in range(0, steps, ig_batch):
+                a = alphas[i0:i0 + ig_batch].view(-1, 1, 1, 1, 1)
+                x = (baseline + a * diff).detach().requires_grad_()
+                with torch.enable_grad():
+                    sim = model(None, x, cls)[0]
+                    sim[:, 0].sum().backward()
+                total += x.grad.sum(dim=0, keepdim=True)
+                model.zero_grad(set_to_none=False)
+        finally:
+            model.gather_negatives = gathered
+            model.train(was_training)
+        return total / steps, diff
+
+    def visualize_integrated_gradients(self, image, text_tokens, labels=None, scan_name="scan", original_scan_path=None,
+                                       steps=50, ig_batch=10):
+        avg, diff = self._integrated_gradients(image, text_tokens, steps=steps, ig_batch=ig_batch)
+        ig = (diff * avg).squeeze().relu()                                   # :879-898
+        ig = (ig - ig.min()) / (ig.max() + 1e-8)
+        ig = ig.cpu().numpy()
+        ig = np.where(ig >= np.quantile(ig, 0.90), ig, 0.0)
+        ig = ig ** 0.05
+        ig = ig / (ig.max() + 1e-8)
+        ig = np.rot90(ig, k=-1, axes=(1, 2))
+        if self.accelerator.is_main_process and self.results_folder is not None:
+            out = self._results_subdirectory("integrated_gradients")
+            np.save(out / f"{scan_name}.npy", ig)
+        return ig
+
     def visualize(self, **kwargs):
         raise NotImplementedError("only occlusion sensitivity (visualize_occlusion_sensitivity / _compute_occlusion) is "
-                                  "implemented on the MI355X path; attention maps, Grad-CAM and integrated gradients are "
-                                  "next rows (SURVEY.md 8f)")
+                                  "and integrated gradients (visualize_integrated_gradients) are implemented on the MI355X "
+                                  "path; attention maps and Grad-CAM are next rows (SURVEY.md 8f)")

@@ -123,6 +123,11 @@ int ctclip_patch_ln_fwd(const void* volume, int volume_is_bf16, const float* gam
 int ctclip_patch_ln_bwd(const void* volume, int volume_is_bf16, const void* dA_bf16, long ldd, const float* mean,
                         const float* rstd, float* dgamma, float* dbeta, int B, int C, int Dz, int Hy, int Wx, int pt,
                         int p, void* stream);
+/* d(volume) [B,C,Dz,Hy,Wx] f32 of the gather + LayerNorm above (input attribution: integrated gradients,
+ * src/utils/visualizations.py:851-910; training never needs it). */
+int ctclip_patch_ln_bwd_dx(const void* volume, int volume_is_bf16, const void* dA_bf16, long ldd, const float* gamma,
+                           const float* mean, const float* rstd, float* dvolume, int B, int C, int Dz, int Hy, int Wx, int pt,
+                           int p, void* stream);
 
 /* ---- row l2-normalisation (VQ input ctvit.py:118; latents ctclip.py:119-120) ---- */
 int ctclip_rownorm_fwd(const float* x, void* y_bf16, float* y_f32, float* inv_norm, long rows, int dim, float eps,

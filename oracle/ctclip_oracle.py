@@ -467,3 +467,35 @@ def occlusion_heatmap(text_inputs, image, st, cfg, patch_size, stride, threshold
         hm[hm < threshold] = 0
         final = np.rot90(hm, k=-1, axes=(1, 2))
     return heat, count, final
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY §8(f) row f1, second half: integrated gradients, restated from reference src/utils/visualizations.py:851-910
+# ---------------------------------------------------------------------------------------------------------------------
+def integrated_gradients(text_inputs, image, st, cfg, steps=50, text_embeds=None):
+    """visualizations.py:851-910 for one process.  Returns (avg_grads [1,1,D,H,W] f32, final map [D,H,W] after the
+    reference's normalise / 0.90-quantile / **0.05 / rot90 post-processing)."""
+    import numpy as np
+    baseline = torch.ones_like(image)                                      # :853-854 (baseline_value = 1)
+    diff = image - baseline
+    grads = []
+    for alpha in torch.linspace(0, 1, steps):                              # :861
+        x = (baseline + alpha * diff).detach().requires_grad_()
+        out = ctclip_forward(text_inputs, x, st, cfg, training=False, text_embeds=text_embeds)
+        out["sim"][0, 0].backward()                                        # :868-869 (rank 0, world size 1)
+        grads.append(x.grad.detach().clone())
+    avg = torch.stack(grads).mean(dim=0)                                   # :878
+    return avg, ig_postprocess(diff, avg)
+
+
+def ig_postprocess(diff, avg_grads):
+    """visualizations.py:879-898."""
+    import numpy as np
+    ig = (diff * avg_grads).squeeze().relu()
+    ig = (ig - ig.min()) / (ig.max() + 1e-8)
+    ig = ig.cpu().numpy()
+    q = np.quantile(ig, 0.90)
+    ig = np.where(ig >= q, ig, 0.0)
+    ig = ig ** 0.05
+    ig = ig / (ig.max() + 1e-8)
+    return np.rot90(ig, k=-1, axes=(1, 2))

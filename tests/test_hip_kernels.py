@@ -334,6 +334,38 @@ def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask, monkeypatch):
         check("attn dbias 2-D grid table", dt2, ref2, 3e-2)
 
 
+# ---------------------------------------------------------------------------------------------- patch embed
+@pytest.mark.parametrize("in16", [False, True])
+def test_patch_ln_forward_and_volume_gradient(hip, in16):
+    """reference src/utils/ctvit.py:44-49 (Rearrange + LayerNorm over the tubelet) and its gradient w.r.t. the VOLUME
+    (ctclip_patch_ln_bwd_dx; used by integrated gradients only), against einops-free torch on the same inputs."""
+    B, C, Dz, Hy, Wx, pt, p = 2, 1, 8, 12, 16, 4, 4
+    F_ = C * pt * p * p
+    vol = rnd(B, C, Dz, Hy, Wx, seed=50)
+    if in16:
+        vol = bf(vol)
+    gm, bt = (1 + 0.3 * rnd(F_, seed=51)), 0.2 * rnd(F_, seed=52)
+    vr = vol.float().clone().requires_grad_(True)
+    t, h, w = Dz // pt, Hy // p, Wx // p
+    rows = vr.view(B, C, t, pt, h, p, w, p).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * t * h * w, F_)
+    ref = torch.nn.functional.layer_norm(rows, (F_,), gm, bt, 1e-5)
+    M, ldA = B * t * h * w, F_
+    A = torch.empty(M, ldA, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.patch_ln_fwd(vol, int(in16), gm, bt, A, mean, rstd, B, C, Dz, Hy, Wx, pt, p, ldA, 1e-5)
+    check("patch ln A", A, ref, 1e-2)
+    dA = bf(rnd(M, ldA, seed=53))
+    ref.backward(dA.float())
+    dvol = torch.empty(B, C, Dz, Hy, Wx, device=DEV)
+    hip.patch_ln_bwd_dx(vol, int(in16), dA, ldA, gm, mean, rstd, dvol, B, C, Dz, Hy, Wx, pt, p)
+    check("patch ln d(volume)", dvol, vr.grad, 2e-5)
+    dg, db = torch.zeros(F_, device=DEV), torch.zeros(F_, device=DEV)
+    hip.patch_ln_bwd(vol, int(in16), dA, ldA, mean, rstd, dg, db, B, C, Dz, Hy, Wx, pt, p)
+    xhat = (rows.detach() - mean[:, None]) * rstd[:, None]
+    check("patch ln dgamma", dg, (dA.float() * xhat).sum(0), 2e-5)
+    check("patch ln dbeta", db, dA.float().sum(0), 2e-5)
+
+
 # ---------------------------------------------------------------------------------------------- PEG
 @pytest.mark.parametrize("B,T,H,W,d", [
     (2, 5, 24, 24, 32),      # the CT-ViT plane: 4 strips of 6 per row, 384 threads

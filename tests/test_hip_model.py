@@ -381,3 +381,36 @@ def test_checkpoint_resume_continues_the_run(tmp_path):
     assert worst <= 1e-3                           # f32 atomics reorder sums; Adam's first steps amplify that to ~1e-4
     with pytest.raises(FileNotFoundError):
         trainer_b.load_model(tmp_path / "missing.pt")
+
+
+def test_integrated_gradients_vs_oracle():
+    """utils.visualizations (reference src/utils/visualizations.py:851-910): batched interpolation points, input gradient
+    through ctclip_patch_ln_bwd_dx, against the oracle's autograd over the same path (VQ codes free-running)."""
+    import numpy as np
+    from oracle import ctclip_oracle as O
+    from utils.visualizations import Visualizations
+
+    class Acc:
+        is_main_process, process_index, num_processes, device = True, 0, 1, torch.device(DEV)
+
+    clip, data, cfg = _config1()
+    st = {k: v.clone() for k, v in clip.state_dict().items()}
+    txt, vol = data[0]
+    txt1 = {k: v[:1] for k, v in txt.items()}
+    image = vol[:1]
+    steps = 6
+    avg_o, map_o = O.integrated_gradients(txt1, image, st, cfg, steps=steps)
+    clip = clip.to(DEV)
+    vis = Visualizations(clip, Acc())
+    avg, diff = vis._integrated_gradients(image, txt1, steps=steps, ig_batch=4)       # 4 + 2: a ragged last batch
+    avg1, _ = vis._integrated_gradients(image, txt1, steps=steps, ig_batch=1)         # the reference's serial schedule
+    check("IG batched vs serial (HIP)", avg, avg1, 1e-3)
+    a, b_ = avg.cpu().reshape(-1).double(), avg_o.reshape(-1).double()
+    cos = float((a @ b_) / (a.norm() * b_.norm()))
+    print(f"  IG average input gradient vs oracle: cosine {cos:.5f}, norm ratio {float(a.norm() / b_.norm()):.4f}")
+    assert cos >= 0.97 and 0.9 <= float(a.norm() / b_.norm()) <= 1.1
+    m = vis.visualize_integrated_gradients(image, txt1, steps=steps, ig_batch=4)
+    assert m.shape == map_o.shape and float(m.max()) <= 1.0 + 1e-6
+    agree = float(((m > 0) == (map_o > 0)).mean())
+    print(f"  IG top-decile mask agreement with the oracle map: {agree:.4f}")
+    assert agree >= 0.93

@@ -23,3 +23,13 @@ for batch in (int(b) for b in os.environ.get("BATCHES", "32,64").split(",")):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"occlusion_batch={batch}: {n} windows in {dt:.2f} s = {n / dt:.1f} windows/s "
           f"(full 12167-window scan: {12167 / (n / dt):.0f} s); peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+
+# integrated gradients (reference visualizations.py:851-910): 50 interpolation points, forward + backward to the volume
+for ig_batch in (10, 25):
+    vis = Visualizations(model, Acc())
+    vis._integrated_gradients(vol, txt, steps=ig_batch, ig_batch=ig_batch)        # warm-up
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    vis._integrated_gradients(vol, txt, steps=50, ig_batch=ig_batch)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"integrated gradients, 50 steps, ig_batch={ig_batch}: {dt:.2f} s ({50 / dt:.1f} fwd+bwd points/s); "
+          f"peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
