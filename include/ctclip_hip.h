@@ -174,6 +174,12 @@ int ctclip_bert_embed_fwd(const long* ids, const long* token_type, const float* 
 int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* dy, float* dword, float* dpos,
                           float* dtype, long rows, int L, int hidden, void* stream);
 
+/* ---- volume ingest (src/utils/preprocess.py:84-152, model_type "ctclip"): raw scan [H,W,D] (f32 or i16) -> HU rescale
+ * -> permute to [D,H,W] -> trilinear resample to (rD,rH,rW) (align_corners=False) -> clamp/1000 -> centre crop / pad with
+ * pad_value to (oD,oH,oW), written as [oD,oH,oW] bf16 or f32 ---- */
+int ctclip_ingest_volume(const void* raw, int raw_is_i16, int H, int W, int D, float slope, float intercept, int rD, int rH,
+                         int rW, int oD, int oH, int oW, float pad_value, void* out, int out_bf16, void* stream);
+
 /* ---- diagnostic: register-resident MFMA 32x32x16 bf16 loop, blocks x 512 threads x iters x 16 MFMAs per wave; times
  * what the matrix pipes sustain at the clock the part holds under load (no reference counterpart) ---- */
 int ctclip_probe_mfma(float* out, int blocks, int iters, void* stream);

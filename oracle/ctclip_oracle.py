@@ -499,3 +499,46 @@ def ig_postprocess(diff, avg_grads):
     ig = ig ** 0.05
     ig = ig / (ig.max() + 1e-8)
     return np.rot90(ig, k=-1, axes=(1, 2))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# volume ingest, restated from reference src/utils/preprocess.py:20-82,123-152
+# ---------------------------------------------------------------------------------------------------------------------
+def preprocess_resize_array(array, current_spacing, target_spacing):
+    """preprocess.py:20-37"""
+    shape = array.shape[2:]
+    factors = [current_spacing[i] / target_spacing[i] for i in range(3)]
+    new_shape = [int(shape[i] * factors[i]) for i in range(3)]
+    return torch.nn.functional.interpolate(array, size=new_shape, mode="trilinear", align_corners=False)
+
+
+def preprocess_crop_and_pad(array, target_shape, pad_value=-1):
+    """preprocess.py:38-82 ([H, W, D] order; centre crop / symmetric pad per axis)"""
+    current = array.shape
+    out = array
+    for i in range(3):
+        size, target = current[i], target_shape[i]
+        if size > target:
+            start = (size - target) // 2
+            out = out.narrow(i, start, target)
+        elif size < target:
+            total = target - size
+            before = total // 2
+            pad = [0, 0, 0, 0, 0, 0]
+            pad[2 * (2 - i)] = before
+            pad[2 * (2 - i) + 1] = total - before
+            out = torch.nn.functional.pad(out, pad, mode="constant", value=pad_value)
+    return out
+
+
+def preprocess_volume(raw_hwd, slope, intercept, xy_spacing, z_spacing, target_shape=(480, 480, 240),
+                      target_spacing=(1.5, 0.75, 0.75)):
+    """preprocess.py:123-152 for model_type 'ctclip'.  raw_hwd [H, W, D] -> [1, D_t, H_t, W_t] f32."""
+    img = torch.as_tensor(raw_hwd).float()
+    img = slope * img + intercept                                          # :124-125
+    img = img.permute(2, 0, 1)[None, None]                                 # :127-131
+    img = preprocess_resize_array(img, (z_spacing, xy_spacing, xy_spacing), target_spacing)   # :133-137
+    img = torch.clamp(img, -1000, 1000) / 1000.0                           # :139-141
+    img = img[0, 0].permute(1, 2, 0)                                       # :145
+    img = preprocess_crop_and_pad(img, target_shape, pad_value=-1)         # :147-149
+    return img.permute(2, 0, 1).unsqueeze(0)                               # :151-152 (+ squeeze(0) of :157)

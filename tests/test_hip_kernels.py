@@ -334,6 +334,33 @@ def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask, monkeypatch):
         check("attn dbias 2-D grid table", dt2, ref2, 3e-2)
 
 
+# ---------------------------------------------------------------------------------------------- volume ingest
+@pytest.mark.parametrize("H,W,D,xy,z,target,i16", [
+    (40, 36, 22, 0.9, 2.4, (48, 40, 30), False),     # up-sampling in every axis; crop in H/W, pad in D
+    (30, 34, 50, 0.6, 1.0, (32, 20, 40), True),      # down-sampling; pad in H, crop in W and D; int16 on the wire
+    (16, 16, 16, 0.75, 1.5, (16, 16, 16), False),    # identity spacing and shape
+])
+def test_volume_ingest_vs_reference_pipeline(hip, H, W, D, xy, z, target, i16):
+    """utils.preprocess.process_volume / ctclip_ingest_volume against the oracle restatement of the reference's tensor
+    pipeline (src/utils/preprocess.py:123-152: HU rescale, permute, trilinear resample, clamp/1000, crop-or-pad with -1)."""
+    from oracle import ctclip_oracle as O
+    from utils.preprocess import process_volume
+    gen = torch.Generator().manual_seed(60)
+    raw = torch.randint(-1200, 2500, (H, W, D), generator=gen).float()
+    slope, intercept = 1.0, -1024.0
+    if i16:
+        raw = raw.to(torch.int16)
+    ref = O.preprocess_volume(raw.float(), slope, intercept, xy, z, target_shape=target).to(DEV)
+    out32 = process_volume(raw, slope, intercept, xy, z, target_shape=target, out_dtype=torch.float32, device=DEV)
+    assert tuple(out32.shape) == tuple(ref.shape) == (1, target[2], target[0], target[1])
+    check("ingest f32", out32, ref, 2e-6)
+    out16 = process_volume(raw, slope, intercept, xy, z, target_shape=target, device=DEV)
+    assert out16.dtype == torch.bfloat16
+    check("ingest bf16", out16, ref, 4e-3)
+    pad_ref = (ref == -1).float().mean()
+    assert abs(float((out32 == -1).float().mean()) - float(pad_ref)) < 1e-3      # same padded region
+
+
 # ---------------------------------------------------------------------------------------------- patch embed
 @pytest.mark.parametrize("in16", [False, True])
 def test_patch_ln_forward_and_volume_gradient(hip, in16):
