@@ -24,6 +24,7 @@
 //     LDS atomics (the CT-ViT bias has only (2h-1)(2w-1) distinct values per head), or, for
 //     arbitrary biases, added to a dense [heads,n,n] buffer with global atomics.
 #include "attn_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -70,14 +71,19 @@ __device__ __forceinline__ void apply_scores(f32x16& s, const float (&add)[16], 
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_fwd_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_base[];
+  char* smem = smem_base;
   constexpr int KS = D / 16, DT = D / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  const int head = blockIdx.y, seq = blockIdx.z;
+  // the block is a.hpb independent groups of waves, one head each (short sequences: one wave per head would otherwise
+  // mean one 64-thread workgroup per (sequence, head) and half-used 128-byte lines)
+  const int nthr = blockDim.x / a.hpb, sub = threadIdx.x / nthr;
+  const int tid = threadIdx.x - sub * nthr, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+  const int head = blockIdx.y * a.hpb + sub, seq = blockIdx.z;
+  smem += (size_t)sub * a.lds_per_head;
   const int half = lane >> 5;
   char* vimg = smem;
   const long row_base = (long)seq * a.n;
-  load_image<D>(vimg, a.v + row_base * a.ldv + head * D, a.ldv, a.n, a.n_pad, tid, blockDim.x);
+  load_image<D>(vimg, a.v + row_base * a.ldv + head * D, a.ldv, a.n, a.n_pad, tid, nthr);
   __syncthreads();
 
   const int q0 = (blockIdx.x * nwaves + wave) * 32;
@@ -154,20 +160,25 @@ __global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_fwd_kernel(AttnArgs 
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(D == 32 ? 384 : 256) void attn_bwd_dq_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_base[];
+  char* smem = smem_base;
   constexpr int KS = D / 16, DT = D / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  const int head = blockIdx.y, seq = blockIdx.z;
+  // the block is a.hpb independent groups of waves, one head each (short sequences: one wave per head would otherwise
+  // mean one 64-thread workgroup per (sequence, head) and half-used 128-byte lines)
+  const int nthr = blockDim.x / a.hpb, sub = threadIdx.x / nthr;
+  const int tid = threadIdx.x - sub * nthr, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+  const int head = blockIdx.y * a.hpb + sub, seq = blockIdx.z;
+  smem += (size_t)sub * a.lds_per_head;
   const int half = lane >> 5;
   char* kimg = smem;
   float* table = (float*)(smem + (size_t)a.n_pad * D * 2);
   int* keyoff = (int*)(table + ((a.table_size + 3) & ~3));
   const long row_base = (long)seq * a.n;
-  load_image<D>(kimg, a.k + row_base * a.ldk + head * D, a.ldk, a.n, a.n_pad, tid, blockDim.x);
+  load_image<D>(kimg, a.k + row_base * a.ldk + head * D, a.ldk, a.n, a.n_pad, tid, nthr);
   if (a.dbias_table) {
-    for (int i = tid; i < a.table_size; i += blockDim.x) table[i] = 0.f;
+    for (int i = tid; i < a.table_size; i += nthr) table[i] = 0.f;
     if (a.grid_w > 0)
-      for (int i = tid; i < a.n_pad; i += blockDim.x) keyoff[i] = (i / a.grid_w) * (2 * a.grid_w - 1) + (i % a.grid_w);
+      for (int i = tid; i < a.n_pad; i += nthr) keyoff[i] = (i / a.grid_w) * (2 * a.grid_w - 1) + (i % a.grid_w);
   }
   __syncthreads();
 
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(D == 32 ? 384 : 256) void attn_bwd_dq_kernel(AttnAr
   }
   if (a.dbias_table) {
     __syncthreads();
-    for (int i = tid; i < a.table_size; i += blockDim.x) {
+    for (int i = tid; i < a.table_size; i += nthr) {
       const float v = table[i];
       if (v != 0.f) atomicAdd(a.dbias_table + (long)head * a.table_size + i, v);
     }
@@ -291,20 +302,25 @@ __global__ __launch_bounds__(D == 32 ? 384 : 256) void attn_bwd_dq_kernel(AttnAr
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(D == 32 ? 384 : 256) void attn_bwd_dkv_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_base[];
+  char* smem = smem_base;
   constexpr int KS = D / 16, DT = D / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  const int head = blockIdx.y, seq = blockIdx.z;
+  // the block is a.hpb independent groups of waves, one head each (short sequences: one wave per head would otherwise
+  // mean one 64-thread workgroup per (sequence, head) and half-used 128-byte lines)
+  const int nthr = blockDim.x / a.hpb, sub = threadIdx.x / nthr;
+  const int tid = threadIdx.x - sub * nthr, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+  const int head = blockIdx.y * a.hpb + sub, seq = blockIdx.z;
+  smem += (size_t)sub * a.lds_per_head;
   const int half = lane >> 5;
   char* qimg = smem;
   char* doimg = smem + (size_t)a.n_pad * D * 2;
   float* lse_s = (float*)(smem + (size_t)a.n_pad * D * 4);
   float* del_s = lse_s + a.n_pad;
   const long row_base = (long)seq * a.n;
-  load_image<D>(qimg, a.q + row_base * a.ldq + head * D, a.ldq, a.n, a.n_pad, tid, blockDim.x);
-  load_image<D>(doimg, a.dO + row_base * a.lddo + head * D, a.lddo, a.n, a.n_pad, tid, blockDim.x);
+  load_image<D>(qimg, a.q + row_base * a.ldq + head * D, a.ldq, a.n, a.n_pad, tid, nthr);
+  load_image<D>(doimg, a.dO + row_base * a.lddo + head * D, a.lddo, a.n, a.n_pad, tid, nthr);
   const long stat_base = ((long)seq * a.heads + head) * a.n;
-  for (int i = tid; i < a.n_pad; i += blockDim.x) {
+  for (int i = tid; i < a.n_pad; i += nthr) {
     lse_s[i] = (i < a.n) ? a.lse[stat_base + i] : INFINITY;   // exp(v - inf) = 0 for padded queries
     del_s[i] = (i < a.n) ? a.delta[stat_base + i] : 0.f;
   }
@@ -385,14 +401,19 @@ __global__ __launch_bounds__(D == 32 ? 384 : 256) void attn_bwd_dkv_kernel(AttnA
 // ------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_probs_kernel(AttnArgs a, float* __restrict__ probs) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_base[];
+  char* smem = smem_base;
   constexpr int KS = D / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  const int head = blockIdx.y, seq = blockIdx.z;
+  // the block is a.hpb independent groups of waves, one head each (short sequences: one wave per head would otherwise
+  // mean one 64-thread workgroup per (sequence, head) and half-used 128-byte lines)
+  const int nthr = blockDim.x / a.hpb, sub = threadIdx.x / nthr;
+  const int tid = threadIdx.x - sub * nthr, lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+  const int head = blockIdx.y * a.hpb + sub, seq = blockIdx.z;
+  smem += (size_t)sub * a.lds_per_head;
   const int half = lane >> 5;
   char* kimg = smem;
   const long row_base = (long)seq * a.n;
-  load_image<D>(kimg, a.k + row_base * a.ldk + head * D, a.ldk, a.n, a.n_pad, tid, blockDim.x);
+  load_image<D>(kimg, a.k + row_base * a.ldk + head * D, a.ldk, a.n, a.n_pad, tid, nthr);
   __syncthreads();
   const int q0 = (blockIdx.x * nwaves + wave) * 32;
   if (q0 >= a.n) return;
@@ -438,6 +459,16 @@ inline int waves_for(int n, int dhead, int cap32 = 9) {
   return cap < 8 ? cap : 8;
 }
 
+// heads per workgroup for short sequences (all row tiles of a head fit one group of `nw` waves): the largest divisor of
+// `heads` whose waves fit the kernel's launch bound and whose LDS regions stay under the default 64 KiB
+inline int heads_per_block(int n_pad, int nw, int heads, int max_waves, size_t lds_per_head) {
+  static const bool off = getenv("CTCLIP_ATTN_HPB1") != nullptr;
+  if (off || n_pad / 32 > nw) return 1;
+  for (int d = heads; d >= 1; --d)
+    if (heads % d == 0 && d * nw <= max_waves && d * lds_per_head <= 65536) return d;
+  return 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -455,8 +486,11 @@ int ctclip_attn_fwd(const void* q, const void* k, const void* v, void* o, float*
     if (e >= 0) return e;
   }
   const int nw = waves_for(n, dhead);
-  dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
-  const size_t lds = (size_t)a.n_pad * dhead * 2;
+  const size_t lds1h = (size_t)a.n_pad * dhead * 2;
+  a.hpb = heads_per_block(a.n_pad, nw, heads, dhead == 32 ? 9 : 4, lds1h);
+  a.lds_per_head = (int)lds1h;
+  dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads / a.hpb, nseq), block(nw * 64 * a.hpb);
+  const size_t lds = lds1h * a.hpb;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   if (dhead == 32) {
     if (lds > 65536) hipFuncSetAttribute((const void*)attn_fwd_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -491,24 +525,29 @@ int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, 
   }
   // both backward passes use 6-wave workgroups: two of them fit per CU at their register budgets (12 resident waves)
   const int nw = waves_for(n, dhead, 6);
-  dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
+  const size_t lds1h = ((size_t)a.n_pad * dhead * 2 +
+                        (a.dbias_table ? (size_t)((table_size + 3) & ~3) * 4 + (size_t)a.n_pad * 4 : 0) + 15) & ~(size_t)15;
+  const size_t lds2h = (size_t)a.n_pad * dhead * 4 + (size_t)a.n_pad * 8;
+  a.hpb = heads_per_block(a.n_pad, nw, heads, dhead == 32 ? 6 : 4, lds1h > lds2h ? lds1h : lds2h);
+  dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads / a.hpb, nseq), block(nw * 64 * a.hpb);
   const int nw2 = nw;
   dim3 grid2 = grid, block2 = block;
-  const size_t lds1 = (size_t)a.n_pad * dhead * 2 +
-                      (a.dbias_table ? (size_t)((table_size + 3) & ~3) * 4 + (size_t)a.n_pad * 4 : 0);
-  const size_t lds2 = (size_t)a.n_pad * dhead * 4 + (size_t)a.n_pad * 8;
+  const size_t lds1 = lds1h * a.hpb, lds2 = lds2h * a.hpb;
   if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
+  AttnArgs a2 = a;                                  // the two passes carve different LDS regions per head
+  a.lds_per_head = (int)lds1h;
+  a2.lds_per_head = (int)lds2h;
   if (dhead == 32) {
     if (lds1 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (lds2 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, lds1, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid2, block2, lds2, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid2, block2, lds2, st, a2);
   } else {
     if (lds1 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     if (lds2 > 65536) hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, lds1, st, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid2, block2, lds2, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid2, block2, lds2, st, a2);
   }
   CTCLIP_CHECK_LAUNCH();
 }
@@ -521,6 +560,8 @@ int ctclip_attn_probs(const void* q, const void* k, const float* lse, const floa
   a.nseq = nseq; a.n = n; a.n_pad = (n + 31) / 32 * 32; a.heads = heads; a.ldq = ldq; a.ldk = ldk; a.scale = scale;
   if (int e = check(a, dhead)) return e;
   const int nw = waves_for(n, dhead);
+  a.hpb = 1;
+  a.lds_per_head = 0;
   dim3 grid((a.n_pad / 32 + nw - 1) / nw, heads, nseq), block(nw * 64);
   const size_t lds = (size_t)a.n_pad * dhead * 2;
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
