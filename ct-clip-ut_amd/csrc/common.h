@@ -48,6 +48,10 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(y, x);
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad_fast(float x) {
+  return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f)) +
+         x * 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+}
 
 // ----- wave-level reductions (64 lanes) -------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

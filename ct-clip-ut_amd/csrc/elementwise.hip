@@ -5,10 +5,7 @@
 namespace {
 
 __device__ __forceinline__ float gelu_f(float x) { return gelu_erf_fast(x); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f)) +
-         x * 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
-}
+__device__ __forceinline__ float gelu_grad_f(float x) { return gelu_erf_grad_fast(x); }
 __device__ __forceinline__ void unpack8(const uint4& r, float (&f)[8]) {
   const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll

@@ -425,6 +425,8 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
                         long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                         hipStream_t st);
 extern "C" int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, int block, long ldh, long ldg, void* stream);
+extern "C" int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, int block, long lddg, long ldh,
+                                void* stream);
 
 extern "C" {
 
@@ -514,6 +516,24 @@ int ctclip_gemm_bf16_geglu(const void* A, const void* Bw, void* H, void* G, int 
   // small problems: the plain product, then the gated activation over the same interleaved layout
   if (int e = ctclip_gemm_bf16(A, Bw, H, nullptr, nullptr, M, N, K, lda, ldb, ldh, 0, 1, 1, 0, 1, 0, 1.0f, 0, stream)) return e;
   return ctclip_geglu_fwd(H, G, M, inner, 64, ldh, ldg, stream);
+}
+
+int ctclip_gemm_bf16_geglu_bwd(const void* dY, const void* W2T, void* H_dH, void* dG_scratch, int M, int inner, int K,
+                               long lddy, long ldw, long ldh, long lddg, void* stream) {
+  if (M <= 0 || inner <= 0) return 0;
+  if ((inner & 63) || K <= 0) return (int)hipErrorInvalidValue;
+  static const bool no_v3 = getenv("CTCLIP_GEMM_NO_V3") != nullptr;
+  static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
+  const long blocks3 = (long)((M + 255) / 256) * ((inner + 255) / 256);
+  const bool aligned = (ldh & 7) == 0 && (((uintptr_t)H_dH) & 15) == 0;
+  if (!no_v3 && aligned && (K % 32) == 0 && (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
+    return ctclip_gemm3_launch(dY, W2T, nullptr, nullptr, nullptr, M, inner, K, lddy, ldw, 0, 0, 0, 1.0f, 3, H_dH, ldh,
+                               (hipStream_t)stream);
+  // small problems: dg into the scratch, then the blocked GEGLU backward in place over h
+  if (!dG_scratch) return (int)hipErrorInvalidValue;
+  if (int e = ctclip_gemm_bf16(dY, W2T, dG_scratch, nullptr, nullptr, M, inner, K, lddy, ldw, lddg, 0, 1, 1, 0, 1, 0, 1.0f, 0, stream))
+    return e;
+  return ctclip_geglu_bwd(dG_scratch, H_dH, H_dH, M, inner, 64, lddg, ldh, stream);
 }
 
 }  // extern "C"

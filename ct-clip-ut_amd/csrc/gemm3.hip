@@ -26,6 +26,7 @@ struct Args {
   int M, N, K, tiles_m, tiles_n, c_fp32, act;
   float alpha;
   bf16_t* G; long ldg;                             // act == 2: gelu(gate) * value of the 64-column interleaved [val|gate] blocks
+                                                   // act == 3: G = h (pre-activations, same blocks), overwritten with d(h)
 };
 
 // [256 rows][32 k] bf16 tile, 64-byte rows, 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128 phase
@@ -185,6 +186,27 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
         float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+        if (act == 3) {
+          // GEGLU backward in the epilogue of dg = dy W2: this tile's dg never goes to memory; the matching value / gate
+          // pre-activations are read from h and replaced by their gradients in place (attention.py:38-41)
+          bf16_t* hv = g.G + (long)row * g.ldg + (long)(col >> 6) * 128 + (col & 63);
+          const uint4 hval = *(const uint4*)hv, hgate = *(const uint4*)(hv + 64);
+          const uint32_t wv[4] = {hval.x, hval.y, hval.z, hval.w}, wg[4] = {hgate.x, hgate.y, hgate.z, hgate.w};
+          float dv[8], dt[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v0 = __uint_as_float(wv[e] << 16), v1 = __uint_as_float(wv[e] & 0xffff0000u);
+            const float t0g = __uint_as_float(wg[e] << 16), t1g = __uint_as_float(wg[e] & 0xffff0000u);
+            dv[2 * e] = v[2 * e] * gelu_erf(t0g); dv[2 * e + 1] = v[2 * e + 1] * gelu_erf(t1g);
+            dt[2 * e] = v[2 * e] * v0 * gelu_erf_grad_fast(t0g); dt[2 * e + 1] = v[2 * e + 1] * v1 * gelu_erf_grad_fast(t1g);
+          }
+          uint4 o0, o1;
+          o0.x = pack_bf16x2(dv[0], dv[1]); o0.y = pack_bf16x2(dv[2], dv[3]); o0.z = pack_bf16x2(dv[4], dv[5]); o0.w = pack_bf16x2(dv[6], dv[7]);
+          o1.x = pack_bf16x2(dt[0], dt[1]); o1.y = pack_bf16x2(dt[2], dt[3]); o1.z = pack_bf16x2(dt[4], dt[5]); o1.w = pack_bf16x2(dt[6], dt[7]);
+          *(uint4*)hv = o0;
+          *(uint4*)(hv + 64) = o1;
+          continue;
+        }
         if (vec && col + 7 < g.N) {
           if (g.bias) {
             const float4 b0 = *(const float4*)(g.bias + col), b1 = *(const float4*)(g.bias + col + 4);
@@ -233,6 +255,8 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
   using namespace g3;
   if ((act & 0xff) == 2 && (c_fp32 || bias || resid || !G || (N & 127) || (ldc & 7) || (ldg & 7) || (((uintptr_t)C) & 15) ||
                             (((uintptr_t)G) & 15)))
+    return (int)hipErrorInvalidValue;
+  if ((act & 0xff) == 3 && (c_fp32 || bias || resid || !G || (N & 63) || (ldg & 7) || (((uintptr_t)G) & 15)))
     return (int)hipErrorInvalidValue;
   // 256 x 256 (one workgroup per CU, 4 stages) is the default: equal to the 256 x 128 / two-workgroup form at K = 512 and
   // 5-10 % ahead at K >= 1408 (profiles/r01_gemm_v3.txt).  CTCLIP_GEMM3_BN=128 selects the latter.

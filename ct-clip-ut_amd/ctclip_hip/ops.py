@@ -473,10 +473,14 @@ class FeedForwardFn(Function):
         gw2, d2 = grad_slot(p_w2)
         glw, d3 = grad_slot(p_lw)
         glb, d4 = grad_slot(p_lb)
-        dg = dgrad(dyb, sh["w2"], M, dim, Ip, out_dtype=BF16, wT16=sh.get("w2T"))
         wgrad(dyb, g, dim, I, M, out=gw2)                          # g's zero pad columns I..Ip-1 are simply not produced
-        dh = torch.empty_like(h)
-        hip.geglu_bwd(dg, h, dh, M, Ip, 64, Ip, 2 * Ip)
+        # dg = dy W2 and the GEGLU backward in one pass: dg stays on chip, h is overwritten with d(h) in place (h is dead
+        # after this; a second backward through the same graph is not supported)
+        w2T = sh["w2T"]
+        small = ((M + 255) // 256) * ((Ip + 255) // 256) < 192
+        scratch = torch.empty(M, Ip, dtype=BF16, device=dy.device) if small else None
+        hip.gemm_bf16_geglu_bwd(dyb, w2T, h, scratch, M, Ip, dim, dyb.stride(0), w2T.stride(0), 2 * Ip, Ip)
+        dh = h
         dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim, out_dtype=BF16, wT16=sh.get("w1T"))
         # one product over all 2*Ip columns of dh (the pad columns are zero): n2 is streamed once and 2*Ip = 2816 is a
         # whole number of 256-row tiles, where two I = 1365-row products each round up to six

@@ -96,6 +96,11 @@ int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inn
  * epilogue (H is still needed by the backward).  inner % 64 == 0, K % 8 == 0. */
 int ctclip_gemm_bf16_geglu(const void* A, const void* Bw, void* H, void* G, int M, int inner, int K, long lda, long ldb,
                            long ldh, long ldg, void* stream);
+/* backward of the same pair: dg = dY[M,K] W2T[inner,K]^T never leaves the chip; the epilogue reads the value / gate
+ * pre-activations from H (64-column interleaved blocks) and overwrites them with their gradients (H_dH in place).
+ * dG_scratch [M, inner] bf16 is only used by the small-problem path (may be NULL for large ones). */
+int ctclip_gemm_bf16_geglu_bwd(const void* dY, const void* W2T, void* H_dH, void* dG_scratch, int M, int inner, int K,
+                               long lddy, long ldw, long ldh, long lddg, void* stream);
 int ctclip_gelu_fwd(const void* h, void* m, long n, void* stream);
 int ctclip_gelu_bwd(const void* dm, const void* h, void* dh, long n, void* stream);
 /* out[b,c,a,:] = in[b,a,c,:] : the spatial<->temporal token re-orderings of ctvit.py:94-101 */

@@ -112,6 +112,21 @@ def test_linear_geglu_fused_and_blocked_backward(hip, M, inner, K):
     dHb = dH.float().view(M, inner // 64, 2, 64)
     check("blocked geglu dval", dHb[:, :, 0].reshape(M, inner), val.grad, 2e-2)
     check("blocked geglu dgate", dHb[:, :, 1].reshape(M, inner), gate.grad, 2e-2)
+    # dg = dY W2 + GEGLU backward in one pass, in place over H (ctclip_gemm_bf16_geglu_bwd)
+    Kd = 96
+    dY = bf(rnd(M, Kd, seed=73))
+    w2 = bf(rnd(Kd, inner, seed=74) * 0.2)                                 # Linear(inner, Kd).weight
+    w2T = w2.t().contiguous()                                              # [inner, Kd]: the k-major operand of dg = dY w2
+    dg_ref = bf(dY.float() @ w2.float())                                   # what the unfused path rounds to bf16
+    val.grad = None
+    gate.grad = None
+    (torch.nn.functional.gelu(gate) * val).backward(dg_ref.float())
+    H2 = H.clone()
+    scratch = torch.empty(M, inner, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16_geglu_bwd(dY, w2T, H2, scratch, M, inner, Kd, Kd, Kd, 2 * inner, inner)
+    H2b = H2.float().view(M, inner // 64, 2, 64)
+    check("fused dgrad+geglu dval", H2b[:, :, 0].reshape(M, inner), val.grad, 2.5e-2)
+    check("fused dgrad+geglu dgate", H2b[:, :, 1].reshape(M, inner), gate.grad, 2.5e-2)
 
 
 def test_gemm_mfma_orientation_asymmetric(hip):
