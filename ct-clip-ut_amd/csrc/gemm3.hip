@@ -49,6 +49,21 @@ __device__ __forceinline__ long piece_src(int p, int lane, int r0, int R, long l
 
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf_fast(x); }
 
+// streaming 16-byte stores of the epilogue (gigabytes written once, read by a later kernel): non-temporal by default,
+// CTCLIP_GEMM3_NO_NT=1 reverts to plain stores
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <bool NT> __device__ __forceinline__ void st16(void* p, uint4 v) {
+  const u32x4_t x = {v.x, v.y, v.z, v.w};
+  if (NT) __builtin_nontemporal_store(x, (u32x4_t*)p);
+  else *(u32x4_t*)p = x;
+}
+template <bool NT> __device__ __forceinline__ void st16f(void* p, float a, float b, float c, float d) {
+  const f32x4_t x = {a, b, c, d};
+  if (NT) __builtin_nontemporal_store(x, (f32x4_t*)p);
+  else *(f32x4_t*)p = x;
+}
+
 #define G3_GLDS(gptr, ldsoff)                                                                                     \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                          \
                                    (__attribute__((address_space(3))) void*)(uintptr_t)(ldsoff), 16, 0, 0)
@@ -57,7 +72,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf_fast(x); }
 // BN = 128: 4 waves (2 x 2), 3-stage ring of 24 KiB = 72 KiB, TWO workgroups per CU: vmcnt is an in-order counter, so a
 //           wave cannot see its next tile's LDS-DMAs complete before its own epilogue stores have drained to HBM; with two
 //           independent workgroups one computes while the other writes back and refills its ring.
-template <int BN, int NS>
+template <int BN, int NS, bool NTS>
 __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
   constexpr int WN = BN / 64, NT = 2 * WN * 64;
   constexpr int STAGE = SUB + BN * BK * 2;
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
           if (g.bias) { const float4 b = *(const float4*)(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
           if (g.resid) { const float4 q = *(const float4*)(g.resid + (long)row * g.ldr + col); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
           if (act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
-          *(float4*)(C + (long)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+          st16f<NTS>(C + (long)row * g.ldc + col, v[0], v[1], v[2], v[3]);
         } else {
           for (int e = 0; e < 4 && col + e < g.N; ++e) {
             float x = v[e] + (g.bias ? g.bias[col + e] : 0.f);
@@ -203,8 +218,8 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
           uint4 o0, o1;
           o0.x = pack_bf16x2(dv[0], dv[1]); o0.y = pack_bf16x2(dv[2], dv[3]); o0.z = pack_bf16x2(dv[4], dv[5]); o0.w = pack_bf16x2(dv[6], dv[7]);
           o1.x = pack_bf16x2(dt[0], dt[1]); o1.y = pack_bf16x2(dt[2], dt[3]); o1.z = pack_bf16x2(dt[4], dt[5]); o1.w = pack_bf16x2(dt[6], dt[7]);
-          *(uint4*)hv = o0;
-          *(uint4*)(hv + 64) = o1;
+          st16<NTS>(hv, o0);
+          st16<NTS>(hv + 64, o1);
           continue;
         }
         if (vec && col + 7 < g.N) {
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
           }
           uint4 o;
           o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-          *(uint4*)(C + (long)row * g.ldc + col) = o;
+          st16<NTS>(C + (long)row * g.ldc + col, o);
           if (act == 2 && ((c8 >> 6) & 1) == 0) {  // a value chunk: its gate sits 64 columns to the right in the same tile
             const float4 g0 = *(const float4*)(ct + r * BN + c8 + 64), g1 = *(const float4*)(ct + r * BN + c8 + 68);
             const float gt[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
             for (int e = 0; e < 8; ++e) w[e] = gelu_erf(gt[e] * g.alpha) * v[e];
             uint4 og;
             og.x = pack_bf16x2(w[0], w[1]); og.y = pack_bf16x2(w[2], w[3]); og.z = pack_bf16x2(w[4], w[5]); og.w = pack_bf16x2(w[6], w[7]);
-            *(uint4*)(g.G + (long)row * g.ldg + (col >> 7) * 64 + (col & 63)) = og;
+            st16<NTS>(g.G + (long)row * g.ldg + (col >> 7) * 64 + (col & 63), og);
           }
         } else {
           for (int e = 0; e < 8 && col + e < g.N; ++e) {
@@ -274,20 +289,24 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
     const size_t lds = (size_t)4 * (SUB + 256 * BK * 2);   // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<256, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      e = hipFuncSetAttribute((const void*)gemm3_kernel<256, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
-    hipLaunchKernelGGL((gemm3_kernel<256, 4>), dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
+    static const bool nt = getenv("CTCLIP_GEMM3_NO_NT") == nullptr;   // non-temporal epilogue stores: +3..6 % on the K = 512 shapes
+    if (nt) hipLaunchKernelGGL((gemm3_kernel<256, 4, true>), dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
+    else hipLaunchKernelGGL((gemm3_kernel<256, 4, false>), dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
   } else {
     const size_t lds = (size_t)3 * (SUB + 128 * BK * 2);   // 72 KiB: two workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<128, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
       attr_set = true;
     }
-    hipLaunchKernelGGL((gemm3_kernel<128, 3>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm3_kernel<128, 3, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, st, g);
   }
   return (int)hipGetLastError();
 }
