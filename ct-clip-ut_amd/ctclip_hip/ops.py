@@ -463,6 +463,10 @@ class FeedForwardFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x2, ln_w, mean, rstd, n2, h, g = ctx.saved_tensors
+        if getattr(ctx, "h_consumed", False):
+            raise RuntimeError("FeedForwardFn.backward ran twice on one graph (retain_graph=True): the GEGLU pre-activations "
+                               "are overwritten by their gradients in place during the first pass")
+        ctx.h_consumed = True
         sh = ctx.sh
         M, dim = x2.shape
         I, Ip = sh["inner"], sh["inner_p"]
