@@ -9,6 +9,7 @@
 // folded into the LDS write address, never into HBM), computes two-pass mean / rstd per tubelet and writes
 // normalised rows with coalesced stores.  Feature index = ((c*pt + pt_i)*p1 + p1_i)*p2 + p2_i.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -17,7 +18,11 @@ struct PatchGeom {
   int Tt, Ht, Wt, F, tpb, wgroups;
   long ldA;
   float eps;
-};
+  unsigned m_p, m_ptp, m_vpr, m_cpt;   // floor(2^32 / d) + 1 for d = p, pt*p, 16-byte vectors per LDS row, chunks per A row:
+};                                      // x / d == __umulhi(x, m) for x * d < 2^32 (one v_mul_hi instead of a ~40-instruction divide)
+
+__host__ __device__ inline unsigned magic_of(unsigned d) { return (unsigned)(0x100000000ull / d) + 1u; }
+__device__ __forceinline__ int fdiv(int x, unsigned m) { return (int)__umulhi((unsigned)x, m); }
 
 template <typename T> __device__ __forceinline__ float ldf(T v);
 template <> __device__ __forceinline__ float ldf<float>(float v) { return v; }
@@ -132,9 +137,9 @@ __device__ __forceinline__ void load_block_vec(char* buf, const TIN* __restrict_
   const int nrows = g.C * g.pt * g.p;
   const int vpr = (g.tpb * g.p * (int)sizeof(TIN)) / 16;               // 16-byte vectors per row
   for (int e = tid; e < nrows * vpr; e += PF_THREADS) {
-    const int rowid = e / vpr, v = e - rowid * vpr;
-    const int c = rowid / (g.pt * g.p), rem = rowid - c * g.pt * g.p;
-    const int pti = rem / g.p, p1i = rem - pti * g.p;
+    const int rowid = fdiv(e, g.m_vpr), v = e - rowid * vpr;
+    const int c = fdiv(rowid, g.m_ptp), rem = rowid - c * g.pt * g.p;
+    const int pti = fdiv(rem, g.m_p), p1i = rem - pti * g.p;
     const long src = ((((long)b * g.C + c) * g.Dz + t * g.pt + pti) * g.Hy + h * g.p + p1i) * g.Wx + (long)w0 * g.p;
     *(uint4*)(buf + (size_t)e * 16) = *(const uint4*)((const char*)(vol + src) + v * 16);
   }
@@ -196,18 +201,35 @@ __global__ __launch_bounds__(PF_THREADS) void patch_ln_fwd_fast(const TIN* __res
   if (tid < g.tpb) { mean[row0 + tid] = smean[tid]; rstd[row0 + tid] = srstd[tid]; }
   const int cpt = (int)(g.ldA >> 3);                                    // 16-byte output chunks per tubelet row
   for (int e = tid; e < g.tpb * cpt; e += PF_THREADS) {
-    const int tok = e / cpt, f0 = (e - tok * cpt) * 8;
+    const int tok = fdiv(e, g.m_cpt), f0 = (e - tok * cpt) * 8;
     const float mu = smean[tok], rs = srstd[tok];
     float o[8];
+    if (f0 + 7 < g.F) {
+      // eight consecutive features: gamma / beta as two float4 each (they were 16 scalar loads per chunk, the kernel's
+      // actual bottleneck), one divide for the first pair and a carry for the rest
+      const float4 g0 = *(const float4*)(gamma + f0), g1 = *(const float4*)(gamma + f0 + 4);
+      const float4 b0 = *(const float4*)(beta + f0), b1 = *(const float4*)(beta + f0 + 4);
+      const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      int rowid = fdiv(f0, g.m_p), c2 = f0 - rowid * g.p;
 #pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-      const int f = f0 + k;
-      if (f < g.F) {
-        const int rowid = f / g.p, c2 = f - rowid * g.p;
+      for (int k = 0; k < 8; k += 2) {
         const float2 v = ld_pair<TIN>(buf, rlb, rowid, tok * g.p + c2);
-        o[k] = (v.x - mu) * rs * gamma[f] + beta[f];
-        o[k + 1] = (v.y - mu) * rs * gamma[f + 1] + beta[f + 1];
-      } else { o[k] = 0.f; o[k + 1] = 0.f; }
+        o[k] = (v.x - mu) * rs * gm[k] + bt[k];
+        o[k + 1] = (v.y - mu) * rs * gm[k + 1] + bt[k + 1];
+        c2 += 2;
+        if (c2 >= g.p) { c2 -= g.p; ++rowid; }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        const int f = f0 + k;
+        if (f < g.F) {
+          const int rowid = fdiv(f, g.m_p), c2 = f - rowid * g.p;
+          const float2 v = ld_pair<TIN>(buf, rlb, rowid, tok * g.p + c2);
+          o[k] = (v.x - mu) * rs * gamma[f] + beta[f];
+          o[k + 1] = (v.y - mu) * rs * gamma[f + 1] + beta[f + 1];
+        } else { o[k] = 0.f; o[k + 1] = 0.f; }
+      }
     }
     uint4 pk;
     pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(PF_THREADS) void patch_ln_bwd_fast(const TIN* __res
       for (int i = 0; i < MAXP; ++i) {
         const int f = (i * PF_THREADS + tid) * 2;
         if (f >= g.F) continue;
-        const int rowid = f / g.p, c2 = f - rowid * g.p;
+        const int rowid = fdiv(f, g.m_p), c2 = f - rowid * g.p;
         for (int tok = 0; tok < g.tpb; ++tok) {
           const uint32_t dw = *(const uint32_t*)(dA + (row0 + tok) * ldd + f);
           const float d0 = __uint_as_float(dw << 16), d1 = __uint_as_float(dw & 0xffff0000u);
@@ -325,12 +347,17 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_dx_kernel(const TIN* __restr
 bool fast_geom(PatchGeom& g, const void* vol, size_t esz, size_t* lds) {
   if ((g.p & 1) || (g.F & 7) || (g.F > 4096) || ((uintptr_t)vol & 15) || (((size_t)g.Wx * esz) & 15)) return false;
   const int nrows = g.C * g.pt * g.p;
+  // LDS budget per workgroup: small enough for several workgroups per CU, whose load / statistics / store phases then
+  // overlap (one 96 KiB workgroup per CU ran them strictly one after the other).  CTCLIP_PATCH_LDS_KB overrides.
+  static const size_t lds_cap = [] { const char* e = getenv("CTCLIP_PATCH_LDS_KB"); return (size_t)(e ? atoi(e) : 32) * 1024; }();   // B=16: 128 KiB 1820/2062 us (fwd/bwd), 48 KiB 1113/959, 32 KiB 1033/967
   for (int tpb = g.Wt; tpb >= 1; --tpb) {
     if (g.Wt % tpb) continue;
     const size_t rlb = (size_t)tpb * g.p * esz;
-    if ((rlb & 15) || nrows * rlb > 128 * 1024) continue;
+    if ((rlb & 15) || nrows * rlb > lds_cap) continue;
     g.tpb = tpb; g.wgroups = g.Wt / tpb;
     *lds = ((nrows * rlb + (size_t)tpb * 8 + 15) & ~(size_t)15);
+    g.m_p = magic_of((unsigned)g.p); g.m_ptp = magic_of((unsigned)(g.pt * g.p));
+    g.m_vpr = magic_of((unsigned)(rlb / 16)); g.m_cpt = magic_of((unsigned)(g.ldA >> 3));
     return true;
   }
   return false;

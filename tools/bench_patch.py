@@ -1,0 +1,26 @@
+"""Micro-benchmark of the tubelet gather + LayerNorm kernels at the production shape."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ct-clip-ut_amd"))
+import torch
+from ctclip_hip.lib import hip
+B = int(os.environ.get("B", 16))
+vol = (torch.randn(B, 1, 240, 480, 480, device="cuda") * 0.5).clamp_(-1, 1).to(torch.bfloat16)
+F_, M = 4000, B * 24 * 24 * 24
+gm, bt = torch.ones(F_, device="cuda"), torch.zeros(F_, device="cuda")
+A = torch.empty(M, F_, device="cuda", dtype=torch.bfloat16)
+mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+dA = torch.randn(M, F_, device="cuda").to(torch.bfloat16)
+dg, db = torch.zeros(F_, device="cuda"), torch.zeros(F_, device="cuda")
+def timeit(fn, n=5):
+    for _ in range(2): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+gb = (vol.numel() * 2 + A.numel() * 2) / 1e9
+t = timeit(lambda: hip.patch_ln_fwd(vol, 1, gm, bt, A, mean, rstd, B, 1, 240, 480, 480, 10, 20, F_, 1e-5))
+print(f"patch_ln_fwd {t:9.1f} us  {gb / t * 1e6 / 1e3:5.2f} TB/s")
+t = timeit(lambda: hip.patch_ln_bwd(vol, 1, dA, F_, mean, rstd, dg, db, B, 1, 240, 480, 480, 10, 20))
+print(f"patch_ln_bwd {t:9.1f} us  {gb / t * 1e6 / 1e3:5.2f} TB/s")
