@@ -441,6 +441,124 @@ __global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_probs_kernel(AttnArg
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// whole backward in one launch for sequences of at most 32 rows and d_head 32 (the temporal attention of the CT-ViT,
+// n = 24, ctvit.py:283-297 -> attention.py:144-183): one wave owns one (sequence, head).  With a single 32x32 score
+// tile there is nothing to sweep, so the two-pass split (and its second read of q/k/v/dO, the delta round trip through
+// HBM and the second launch) buys nothing; the wave instead forms the tile in both orientations -- [key][q] feeds dQ,
+// [q][key] feeds dK and dV as the accumulator-as-operand trick needs -- from the same ten operand fragments, which
+// serve as A or B operand alike.  Three wave-private 2 KiB images (K, Q, dO) supply the transposed reads; no block
+// barrier anywhere.  Not used when a bias gradient is requested.
+// ------------------------------------------------------------------------------------------------
+constexpr int SMALL_WAVE_LDS = 3 * 2048 + 256;
+__global__ __launch_bounds__(512) void attn_small_bwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_base[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (item >= (long)a.nseq * a.heads) return;
+  const int seq = (int)(item / a.heads), head = (int)(item % a.heads);
+  const int r = lane & 31, half = lane >> 5;
+  char* kimg = smem_base + (size_t)wave * SMALL_WAVE_LDS;
+  char* qimg = kimg + 2048;
+  char* doimg = qimg + 2048;
+  float* lse_s = (float*)(doimg + 2048);
+  float* del_s = lse_s + 32;
+  const bool valid = r < a.n;                       // lane's row: a query in the first orientation, a key in the second
+  const int rc = valid ? r : a.n - 1;
+  const long row = (long)seq * a.n + rc;
+  const long hoff = (long)head * 32;
+  bf16x8 qf[2], kf[2], vf[2], dof[2], of[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    qf[s] = gfrag(a.q + row * a.ldq + hoff, s, lane, valid);
+    kf[s] = gfrag(a.k + row * a.ldk + hoff, s, lane, valid);
+    vf[s] = gfrag(a.v + row * a.ldv + hoff, s, lane, valid);
+    dof[s] = gfrag(a.dO + row * a.lddo + hoff, s, lane, valid);
+    of[s] = gfrag(a.oin + row * a.ldo + hoff, s, lane, valid);
+  }
+  const long stat = ((long)seq * a.heads + head) * a.n;
+  const float lse = valid ? a.lse[stat + r] : INFINITY;    // exp(v - inf) = 0 for padded queries
+  float dsum = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dsum += (float)dof[s][j] * (float)of[s][j];
+  dsum += __shfl_xor(dsum, 32, 64);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    *(bf16x8*)(kimg + img_off<32>(r, 2 * s + half)) = kf[s];
+    *(bf16x8*)(qimg + img_off<32>(r, 2 * s + half)) = qf[s];
+    *(bf16x8*)(doimg + img_off<32>(r, 2 * s + half)) = dof[s];
+  }
+  if (half == 0) {
+    lse_s[r] = lse;
+    del_s[r] = dsum;
+    if (valid && a.delta) a.delta[stat + r] = dsum;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  f32x16 s, dp, out[1];
+  // ---- [key][q]: lane = query r -> dQ
+  zero_acc(s);
+  zero_acc(dp);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    s = mfma32(kf[ks], qf[ks], s);
+    dp = mfma32(vf[ks], dof[ks], dp);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int key = acc_row(i, half), key_c = key < a.n ? key : a.n - 1;
+    float v = s[i] * a.scale;
+    if (a.bias) v += a.bias[((long)head * a.n + rc) * a.n + key_c];
+    if (a.mask) v += a.mask[(long)seq * a.n + key_c];
+    const float p = (valid && key < a.n) ? __expf(v - lse) : 0.f;
+    s[i] = p * (dp[i] - dsum);                      // dS^T[key][q]
+  }
+  {
+    const bf16x8 d0 = acc_frag(s, 0), d1 = acc_frag(s, 1);
+    zero_acc(out[0]);
+    out[0] = mfma32(tr_frag<32>(kimg, 0, 0, 0, lane), d0, out[0]);
+    out[0] = mfma32(tr_frag<32>(kimg, 0, 1, 0, lane), d1, out[0]);
+    if (valid) store_rows<32>(a.dq + ((long)seq * a.n + r) * a.lddq + hoff, out, a.scale, lane);
+  }
+  // ---- [q][key]: lane = key r -> dV, dK
+  zero_acc(s);
+  zero_acc(dp);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    s = mfma32(qf[ks], kf[ks], s);
+    dp = mfma32(dof[ks], vf[ks], dp);
+  }
+  const float mval = (a.mask && valid) ? a.mask[(long)seq * a.n + r] : 0.f;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int qb = 8 * g4 + 4 * half;
+    const float4 l4 = *(const float4*)(lse_s + qb);
+    const float4 d4 = *(const float4*)(del_s + qb);
+    const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = s[4 * g4 + i] * a.scale + mval;
+      if (a.bias) v += a.bias[((long)head * a.n + (qb + i < a.n ? qb + i : a.n - 1)) * a.n + rc];
+      const float p = valid ? __expf(v - ls[i]) : 0.f;
+      s[4 * g4 + i] = p;
+      dp[4 * g4 + i] = p * (dp[4 * g4 + i] - de[i]);
+    }
+  }
+  const bf16x8 p0 = acc_frag(s, 0), p1 = acc_frag(s, 1), d0 = acc_frag(dp, 0), d1 = acc_frag(dp, 1);
+  zero_acc(out[0]);
+  out[0] = mfma32(tr_frag<32>(doimg, 0, 0, 0, lane), p0, out[0]);
+  out[0] = mfma32(tr_frag<32>(doimg, 0, 1, 0, lane), p1, out[0]);
+  if (valid) store_rows<32>(a.dv + ((long)seq * a.n + r) * a.lddv + hoff, out, 1.0f, lane);
+  zero_acc(out[0]);
+  out[0] = mfma32(tr_frag<32>(qimg, 0, 0, 0, lane), d0, out[0]);
+  out[0] = mfma32(tr_frag<32>(qimg, 0, 1, 0, lane), d1, out[0]);
+  if (valid) store_rows<32>(a.dk + ((long)seq * a.n + r) * a.lddk + hoff, out, a.scale, lane);
+}
+
 int check(const AttnArgs& a, int dhead) {
   if (dhead != 32 && dhead != 64) return (int)hipErrorInvalidValue;
   if (a.n <= 0 || a.nseq <= 0 || a.heads <= 0) return (int)hipErrorInvalidValue;
@@ -522,6 +640,14 @@ int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, 
   {
     const int e = ctclip_attn_sp_bwd(a, dhead, (hipStream_t)stream);
     if (e >= 0) return e;
+  }
+  static const bool no_small = getenv("CTCLIP_ATTN_NO_SMALL") != nullptr;
+  if (dhead == 32 && n <= 32 && !a.dbias_dense && !a.dbias_table && !no_small) {
+    const long items = (long)nseq * heads;
+    const int wpb = 8;
+    hipLaunchKernelGGL(attn_small_bwd_kernel, dim3((unsigned)((items + wpb - 1) / wpb)), dim3(wpb * 64),
+                       (size_t)wpb * SMALL_WAVE_LDS, (hipStream_t)stream, a);
+    CTCLIP_CHECK_LAUNCH();
   }
   // both backward passes use 6-wave workgroups: two of them fit per CU at their register budgets (12 resident waves)
   const int nw = waves_for(n, dhead, 6);

@@ -283,6 +283,8 @@ def attn_ref(q, k, v, bias, mask, scale):
     (1, 512, 2, 64, False, True),      # BERT L=512 (128 KiB of LDS)
     (7, 320, 3, 32, True, False),      # sequence-persistent kernels, 10 tiles over 8 waves (2 + 1 per wave)
     (5, 256, 2, 32, False, False),     # sequence-persistent kernels without a bias
+    (5, 24, 3, 32, False, True),       # one-wave fused backward: masked keys, 15 (sequence, head) items over 8-wave groups
+    (3, 32, 2, 32, True, False),       # one-wave fused backward at its largest row count, bias as an input only
 ])
 def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask, monkeypatch):
     scale = 1.0 if D == 32 else 1.0 / math.sqrt(D)
@@ -328,6 +330,14 @@ def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask, monkeypatch):
     check("attn dv", un(dv), vr.grad, 3e-2)
     if use_bias:
         check("attn dbias dense", dbias, br.grad, 3e-2)
+        # bias as an input only (no bias gradient asked for): n <= 32 takes the one-wave fused backward
+        for t in (dq, dk, dv):
+            t.zero_()
+        hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, mask, None, None, None, 0, 0, 0, nseq, n, H, D,
+                     ld, ld, ld, ld, ld, ld, ld, ld, scale)
+        check("attn dq (no dbias)", un(dq), qr.grad, 3e-2)
+        check("attn dk (no dbias)", un(dk), kr.grad, 3e-2)
+        check("attn dv (no dbias)", un(dv), vr.grad, 3e-2)
         # table mode: bias[h,i,j] = table[h, relidx[i,j]]; d(table) = scatter-add of d(bias)
         R = 37
         relidx = torch.randint(0, R, (n, n), generator=torch.Generator().manual_seed(3)).to(DEV)
