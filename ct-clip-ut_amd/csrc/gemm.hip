@@ -424,6 +424,8 @@ int ctclip_gemm2_launch(const void* A, const void* B, void* C, const float* bias
 int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                         long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                         hipStream_t st);
+int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
+                        float alpha, hipStream_t st);
 extern "C" int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, int block, long ldh, long ldg, void* stream);
 extern "C" int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, int block, long lddg, long ldh,
                                 void* stream);
@@ -455,6 +457,13 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
         (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
       return ctclip_gemm3_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, nullptr, 0,
                                  (hipStream_t)stream);
+    // weight gradients (m-major x n-major, split over the tokens, f32 atomics) with enough 256 x 256 x split workgroups go
+    // to gemm4.hip, the transposed-operand form of the same tile.  CTCLIP_GEMM_NO_V4=1 disables it.
+    static const bool no_v4 = getenv("CTCLIP_GEMM_NO_V4") != nullptr;
+    const long blocks4 = blocks3 * (split_k > 1 ? split_k : 1);
+    if (!no_v4 && !force_v1 && !a_kmajor && !b_kmajor && accumulate && c_fp32 && !bias && !resid && (K % 32) == 0 &&
+        (blocks4 >= 128 || v2_all))
+      return ctclip_gemm4_launch(A, B, C, M, N, K, lda, ldb, ldc, split_k, alpha, (hipStream_t)stream);
     const long blocks2 = (long)((M + 255) / 256) * ((N + 127) / 128) * (split_k > 1 ? split_k : 1);
     const bool eligible = !force_v1 && (K % 64) == 0 && blocks2 >= 192;
     if (eligible || (v2_all && !force_v1 && (K % 64) == 0 && blocks2 >= 8))

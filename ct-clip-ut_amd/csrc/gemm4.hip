@@ -1,0 +1,205 @@
+// bf16 MFMA GEMM, 256 x 256 x 32 tile for the weight gradients of the CT-CLIP step:
+//   dW[M,N] += alpha * A[K,M]^T B[K,N]   (A = dy, B = x, both row-major over K = all tokens, i.e. m-major x n-major),
+// split over K with f32 atomics into a zeroed / running dW (torch.nn.Linear's backward, attention.py:55-70, 144-183).
+//
+// These products have a tiny output and a contraction of ~10^6, so they are pure main loop.  gemm2.hip ran them on its
+// 256 x 128 x 64 tile (85 FLOP per operand byte, two 48 KiB stages in flight).  Here the tile of gemm3.hip is used with
+// the operands stored the other way round:
+//   * block tile 256 x 256 x 32, 512 threads = 8 waves (2 x 4), each wave 128 x 64 as 4x2 MFMA 32x32x16;
+//   * a stage holds A[32 k][256 m] and B[32 k][256 n] (512-byte k-rows, 32 KiB), ring of four stages; global_load_lds
+//     moves two whole k-rows per wave-instruction, the bank swizzle applied to the SOURCE column chunk;
+//   * fragments come out of LDS with ds_read_b64_tr_b16 (the MFMA wants 8 consecutive k per lane, memory has 8
+//     consecutive m): twelve transposed reads per 16-wide k-step and wave, issued as inline asm (see gemm2.hip) and
+//     double-buffered -- the reads of k-step s+1 are in flight under the MFMAs of k-step s;
+//   * epilogue: f32 atomics straight from the accumulators (each register covers two 128-byte row segments).
+// Preconditions (checked by the dispatcher in gemm.hip): both operands m/n-major, K % 32 == 0, f32 accumulate output.
+#include "common.h"
+
+namespace g4 {
+
+constexpr int BM = 256, BN = 256, BK = 32, NS = 4, NT = 512;
+constexpr int SUB = 16384;                 // one operand tile of a stage: 32 k-rows x 256 columns of bf16
+constexpr int STAGE = 2 * SUB;
+constexpr int PPW = (STAGE / 1024) / (NT / 64);   // 4 LDS-DMA pieces of 1 KiB per wave and stage
+
+struct Args {
+  const bf16_t* A; const bf16_t* B; float* C;
+  long lda, ldb, ldc;
+  int M, N, K, tiles_m, tiles_n, split_k, ktiles_per_split;
+  float alpha;
+};
+
+// [32 k][256 cols] bf16 tile, 512-byte rows of 32 16-byte chunks.  A transposed read touches, per 16-lane group, four
+// k-rows (k & 3) x 32 bytes; the XOR moves those rows to different bank groups and the two k-halves apart.
+__device__ __forceinline__ uint32_t swz(int k) { return (uint32_t)(((k & 3) << 2) | ((k >> 2) & 3)); }
+__device__ __forceinline__ uint32_t tile_off(int k, int chunk) { return (uint32_t)(k * 512) + (((uint32_t)chunk ^ swz(k)) << 4); }
+
+__device__ __forceinline__ short4v tr_read_asm(uint32_t lds_addr) {
+  short4v r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_addr));
+  return r;
+}
+// s_waitcnt lgkmcnt(0) that data-depends on every register of one fragment set: its consumers cannot move above it
+__device__ __forceinline__ void tr_wait(short4v (&p)[12]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]),
+                 "+v"(p[8]), "+v"(p[9]), "+v"(p[10]), "+v"(p[11])
+               :
+               : "memory");
+}
+// raw halves of the fragment  element j = T[k = 16s + 8*(lane>>5) + j][cbase + (lane&31)]
+__device__ __forceinline__ void read_frag_tr(uint32_t tile_lds, int cbase, int s, int lane, short4v& lo, short4v& hi) {
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3, h = g >> 1;
+  const int c0 = cbase + 16 * (g & 1) + 4 * p;
+  const int klo = 16 * s + 8 * h + q;
+  const uint32_t sub = (uint32_t)((p & 1) * 8);
+  lo = tr_read_asm(tile_lds + tile_off(klo, c0 >> 3) + sub);
+  hi = tr_read_asm(tile_lds + tile_off(klo + 4, c0 >> 3) + sub);
+}
+
+// element offset (from the operand base, at k-tile 0) of the 16 bytes lane `lane` contributes to 1 KiB piece `p`
+// (k-rows 2p, 2p+1) of the tile whose first column is c0; its LDS destination is piece_base + lane*16
+__device__ __forceinline__ long piece_src(int p, int lane, int c0, int R, long ld) {
+  const int k = 2 * p + (lane >> 5), pc = lane & 31, c = pc ^ (int)swz(k);
+  int col = c0 + c * 8;
+  if (col >= R) col = 0;                           // masked in the epilogue
+  return (long)k * ld + col;
+}
+
+#define G4_GLDS(gptr, ldsoff)                                                                                     \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                          \
+                                   (__attribute__((address_space(3))) void*)(uintptr_t)(ldsoff), 16, 0, 0)
+
+__global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % g.tiles_n; bid /= g.tiles_n;
+  const int tm = bid % g.tiles_m;
+  const int ks = bid / g.tiles_m;
+  const int row0 = tm * BM, col0 = tn * BN;
+  const int nk_total = g.K / BK;
+  const int kt_begin = ks * g.ktiles_per_split;
+  const int nk = min(nk_total, kt_begin + g.ktiles_per_split) - kt_begin;
+
+  // piece q = wave * PPW + j of a stage: the first 16 are the A tile, the rest the B tile (stored right behind it)
+  const bf16_t* src[PPW];
+  long kstep[PPW];
+  uint32_t dst[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int q = wave * PPW + j;
+    if (q < 16) {
+      src[j] = g.A + piece_src(q, lane, row0, g.M, g.lda) + (long)kt_begin * BK * g.lda;
+      kstep[j] = (long)BK * g.lda;
+    } else {
+      src[j] = g.B + piece_src(q - 16, lane, col0, g.N, g.ldb) + (long)kt_begin * BK * g.ldb;
+      kstep[j] = (long)BK * g.ldb;
+    }
+    dst[j] = (uint32_t)(q * 1024);
+  }
+  auto issue_part = [&](int t, int j0) {           // half of this wave's pieces of K-step t -> stage t % NS
+    const uint32_t sb = lds0 + (uint32_t)((t % NS) * STAGE);
+#pragma unroll
+    for (int j = j0; j < j0 + PPW / 2; ++j) G4_GLDS(src[j] + (long)t * kstep[j], sb + dst[j]);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < nk) { issue_part(t, 0); issue_part(t, PPW / 2); }
+
+  auto read_set = [&](short4v (&raw)[12], uint32_t sa_l, int s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) read_frag_tr(sa_l, wm * 128 + i * 32, s, lane, raw[2 * i], raw[2 * i + 1]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) read_frag_tr(sa_l + SUB, wn * 64 + j * 32, s, lane, raw[8 + 2 * j], raw[9 + 2 * j]);
+  };
+  auto mma_set = [&](short4v (&raw)[12]) {
+    bf16x8 fa[4], fb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = join_tr(raw[2 * i], raw[2 * i + 1]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[j] = join_tr(raw[8 + 2 * j], raw[9 + 2 * j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+  };
+
+  for (int t = 0; t < nk; ++t) {
+    // K-step t must have landed; the PPW LDS-DMAs of each of the (up to NS-2) younger steps may stay in flight across the barrier
+    const int younger = nk - 1 - t;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // also: every wave is done reading stage (t+3) % NS (K-step t-1)
+    const bool pre = t + NS - 1 < nk;
+    const uint32_t sa_l = lds0 + (uint32_t)((t % NS) * STAGE);
+    short4v r0[12], r1[12];
+    read_set(r0, sa_l, 0);
+    if (pre) issue_part(t + NS - 1, 0);
+    tr_wait(r0);
+    read_set(r1, sa_l, 1);                         // in flight under the MFMAs of the first half
+    if (pre) issue_part(t + NS - 1, PPW / 2);
+    mma_set(r0);
+    __builtin_amdgcn_sched_barrier(0);             // keep the first half's MFMAs in front of the wait
+    tr_wait(r1);
+    mma_set(r1);
+  }
+
+  // split-K: f32 atomics straight from the accumulators.  For a fixed register the 64 lanes cover two 128-byte row
+  // segments -- the access shape global_atomic_add_f32 runs at full rate with.
+  const int half = lane >> 5, lc = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = col0 + wn * 64 + j * 32 + lc;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 128 + i * 32 + acc_row(r, half);
+        if (row >= g.M) continue;
+        atomicAdd(g.C + (long)row * g.ldc + col, acc[i][j][r] * g.alpha);
+      }
+    }
+}
+
+}  // namespace g4
+
+// called by ctclip_gemm_bf16 (gemm.hip): m-major x n-major, K % 32 == 0, f32 accumulate output
+int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
+                        float alpha, hipStream_t st) {
+  using namespace g4;
+  Args g{};
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = (float*)C;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  const int nk = K / BK;
+  if (split_k < 1) split_k = 1;
+  if (split_k > nk) split_k = nk;
+  g.ktiles_per_split = (nk + split_k - 1) / split_k;
+  g.split_k = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
+  g.alpha = alpha;
+  const size_t lds = (size_t)NS * STAGE;           // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm4_kernel, dim3(g.tiles_m * g.tiles_n * g.split_k), dim3(NT), lds, st, g);
+  return (int)hipGetLastError();
+}

@@ -89,12 +89,14 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_dtype=BF1
 
 
 def _splits_for(m_out: int, n_out: int, k: int) -> int:
-    """split-K factor of a weight-gradient GEMM (small m_out x n_out, contraction over all tokens): about two waves of
-    256x128 workgroups on the 256 CUs (the pipelined kernel runs one workgroup per CU), at least 8 k-tiles per split."""
+    """split-K factor of a weight-gradient GEMM (small m_out x n_out, contraction over all tokens): at most two
+    workgroups of the 256x256x32 kernel (gemm4.hip, one resident per CU) for each of the 256 CUs, never a third partial
+    round, and at least 8 k-tiles per split."""
+    if k % 32 == 0:
+        nk = k // 32
+        tiles = ((m_out + 255) // 256) * ((n_out + 255) // 256)
+        return max(1, min(nk // 8 if nk >= 8 else 1, max(1, 512 // tiles)))
     nk = (k + 63) // 64
-    if k % 64 == 0:
-        tiles = ((m_out + 255) // 256) * ((n_out + 127) // 128)
-        return max(1, min(nk // 8 if nk >= 8 else 1, (512 + tiles - 1) // tiles))
     tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
     return max(1, min(nk, (1024 + tiles - 1) // tiles))
 

@@ -87,6 +87,28 @@ def test_gemm_pipelined_variant(hip, akm, bkm, M, N, K, split):
     check(f"gemm2 bf16 gelu ({akm},{bkm})", C16, torch.nn.functional.gelu(ref), 1e-2)
 
 
+@pytest.mark.parametrize("M,N,K,split", [(512, 768, 4096, 5),     # interior tiles, uneven last split
+                                         (2816, 512, 2048, 3),    # FF1 weight-gradient shape (11 x 2 tiles)
+                                         (520, 1408, 1024, 4),    # ragged in both directions (FF2: 5.5 tiles)
+                                         (256, 264, 96, 2),       # fewer K-steps (3) than ring stages
+                                         (72, 40, 32, 1)])        # one K-step, one partial tile
+def test_gemm_weight_gradient_kernel(hip, M, N, K, split):
+    """dW += alpha dy^T x with both operands row-major over the tokens (torch.nn.Linear backward): the 256x256x32
+    transposed-operand kernel (csrc/gemm4.hip) with split-K atomics into a running sum."""
+    A, B = bf(rnd(K, M, seed=1)), bf(rnd(K, N, seed=2))
+    ref = A.float().t() @ B.float()
+    run = rnd(M, N, seed=6)
+    C = run.clone()
+    hip.gemm_bf16(A, B, C, None, None, M, N, K, M, N, N, 0, 0, 0, 1, split, 1, 0.5, 0)
+    check(f"wgrad {M}x{N}x{K} split {split}", C, 0.5 * ref + run, 2e-3)
+    # strided operands (column slices of wider buffers, as the fused q/kv gradients are)
+    Aw, Bw = bf(rnd(K, M + 64, seed=3)), bf(rnd(K, N + 128, seed=4))
+    C2 = torch.zeros(M, N + 8, device=DEV)
+    hip.gemm_bf16(Aw[:, 64:], Bw[:, 128:], C2, None, None, M, N, K, M + 64, N + 128, N + 8, 0, 0, 0, 1, split, 1, 1.0, 0)
+    check("wgrad strided", C2[:, :N], Aw[:, 64:].float().t() @ Bw[:, 128:].float(), 2e-3)
+    assert float(C2[:, N:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("M,inner,K", [(3000, 384, 96), (2100, 128, 64), (70, 64, 40)])
 def test_linear_geglu_fused_and_blocked_backward(hip, M, inner, K):
     """ctclip_gemm_bf16_geglu (reference attention.py:38-50): interleaved [val 64 | gate 64] weight rows, H and

@@ -21,8 +21,9 @@ shapes = [  # name, M, N, K, akm, bkm, c_fp32, split, accumulate   (I = 1365, pa
     ("out dgrad", T, 256, 512, 1, 1, 0, 1, 0),
     ("q dgrad f32", T, 512, 256, 1, 1, 1, 1, 0),
     ("kv dgrad f32", T, 512, 512, 1, 1, 1, 1, 0),
-    ("ff1 wgrad half", 1365, 512, T, 0, 0, 1, 0, 1),
-    ("ff2 wgrad", 512, 1365, T, 0, 0, 1, 0, 1),
+    ("ff1 wgrad", 2816, 512, T, 0, 0, 1, 0, 1),
+    ("ff2 wgrad", 512, 1408, T, 0, 0, 1, 0, 1),
+    ("out wgrad", 512, 256, T, 0, 0, 1, 0, 1),
     ("kv wgrad", 512, 512, T, 0, 0, 1, 0, 1),
     ("q wgrad", 256, 512, T, 0, 0, 1, 0, 1),
     ("patch wgrad", 512, 4000, T, 0, 0, 1, 0, 1),
