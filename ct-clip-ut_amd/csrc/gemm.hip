@@ -426,6 +426,8 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
                         hipStream_t st);
 int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
                         float alpha, hipStream_t st);
+int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
+                           long ldb, hipStream_t st);
 extern "C" int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, int block, long ldh, long ldg, void* stream);
 extern "C" int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, int block, long lddg, long ldh,
                                 void* stream);
@@ -489,6 +491,10 @@ int ctclip_vq_topk(const void* A, const void* B, float* part_val, int* part_idx,
                    void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true)) return (int)hipErrorInvalidValue;
+  // whole 256-code tiles: the 256 x 256 LDS-DMA form in gemm3.hip (CTCLIP_VQ_NO_V3=1 keeps the kernel below)
+  static const bool no_v3 = getenv("CTCLIP_VQ_NO_V3") != nullptr;
+  if (!no_v3 && (M % 256) == 0 && (K % 32) == 0)
+    return ctclip_vq_topk3_launch(A, B, part_val, part_idx, M, N, K, lda, ldb, (hipStream_t)stream);
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;

@@ -261,6 +261,137 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// VQ nearest-code search on the same tile and ring (vector_quantize_pytorch cosine-sim codebook, ctvit.py:420-427):
+// scores[code][token] = sum_k A[code][k] B[token][k] are never written.  One workgroup owns 256 tokens and sweeps ALL
+// 256-code tiles; the (code tile, K-step) sequence is flattened so the ring never drains between tiles.  Every lane
+// keeps a running top-4 (value, code) for each of its two token columns over the 64 codes per tile its accumulator
+// registers cover; a token ends with 4 lane groups (wm, lane half) x 4 = 16 candidates from disjoint parts of the
+// codebook, which ctclip_vq_select re-ranks exactly in f32.  Against the 128 x 128 register-staged kernel of gemm.hip
+// this halves the operand bytes pulled through L2 per flop (the codebook is re-streamed once per 256 tokens, not 128).
+// Preconditions (gemm.hip): M % 256 == 0, K % 32 == 0.
+// ------------------------------------------------------------------------------------------------------------------
+struct VqArgs {
+  const bf16_t* A; const bf16_t* B;
+  long lda, ldb;
+  int M, N, K, tiles_m;
+  float* part_val; int* part_idx;
+};
+constexpr int VQ_TOP = 4;                       // the insertion below is written out for exactly four places
+
+__global__ __launch_bounds__(512, 2) void vq_topk3_kernel(VqArgs g) {
+  constexpr int BN = 256, NS = 4, WN = 4, STAGE = 2 * SUB, PPW = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int col0 = xcd_remap(blockIdx.x, gridDim.x) * BN;      // token tile
+  const int nk = g.K / BK;
+  const int steps = g.tiles_m * nk;                            // flattened (code tile, K-step) sequence
+  const int half = lane >> 5, lc = lane & 31;
+
+  const bf16_t* src[PPW];
+  long tstep[PPW];
+  uint32_t dst[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int q = wave * PPW + j;
+    if (q < 16) { src[j] = g.A + piece_src(q, lane, 0, g.M, g.lda); tstep[j] = (long)BM * g.lda; }
+    else { src[j] = g.B + piece_src(q - 16, lane, col0, g.N, g.ldb); tstep[j] = 0; }
+    dst[j] = (uint32_t)(q * 1024);
+  }
+  int pf = 0, pf_tile = 0, pf_k = 0;                           // the next step to request: index, its code tile and K-step
+  auto issue_part = [&](int j0) {
+    const uint32_t sb = lds0 + (uint32_t)((pf % NS) * STAGE);
+#pragma unroll
+    for (int j = j0; j < j0 + PPW / 2; ++j) G3_GLDS(src[j] + (long)pf_tile * tstep[j] + (long)pf_k * BK, sb + dst[j]);
+  };
+  auto advance = [&]() {
+    ++pf;
+    if (++pf_k == nk) { pf_k = 0; ++pf_tile; }
+  };
+
+  float bv[2][VQ_TOP];
+  int bi[2][VQ_TOP];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int t = 0; t < VQ_TOP; ++t) { bv[j][t] = -INFINITY; bi[j][t] = 0x7fffffff; }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < steps) { issue_part(0); issue_part(PPW / 2); advance(); }
+
+  int kt = 0, tile = 0;
+  for (int st = 0; st < steps; ++st) {
+    const int younger = steps - 1 - st;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool pre = pf < steps;
+    const char* sa = smem + (st % NS) * STAGE;
+    const char* sb = sa + SUB;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag(sa, wm * 128 + i * 32, s, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = read_frag(sb, wn * 64 + j * 32, s, lane);
+      if (pre) issue_part(s * (PPW / 2));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+    }
+    if (pre) advance();
+    if (++kt == nk) {                                          // a code tile is complete: fold it into the running top-4
+      kt = 0;
+      const int row_t = tile * BM + wm * 128;
+      ++tile;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            const int row = row_t + i * 32 + acc_row(r, half);
+            // A lane meets its codes in ascending order (tile, i, r), so a newcomer never outranks an equal score
+            // already listed: strict compares alone keep the list sorted by (score desc, code asc).  Entries below the
+            // insertion point move down one place.
+            if (v > bv[j][3]) {
+              const bool c2 = v > bv[j][2], c1 = v > bv[j][1], c0 = v > bv[j][0];
+              bv[j][3] = c2 ? bv[j][2] : v;                        bi[j][3] = c2 ? bi[j][2] : row;
+              bv[j][2] = c1 ? bv[j][1] : (c2 ? v : bv[j][2]);      bi[j][2] = c1 ? bi[j][1] : (c2 ? row : bi[j][2]);
+              bv[j][1] = c0 ? bv[j][0] : (c1 ? v : bv[j][1]);      bi[j][1] = c0 ? bi[j][0] : (c1 ? row : bi[j][1]);
+              bv[j][0] = c0 ? v : bv[j][0];                        bi[j][0] = c0 ? row : bi[j][0];
+            }
+            acc[i][j][r] = 0.f;
+          }
+    }
+  }
+  // candidates: [token][ (wm*2 + half) * VQ_TOP + t ]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + wn * 64 + j * 32 + lc;
+    if (col >= g.N) continue;
+    const long p = (long)col * (4 * VQ_TOP) + (wm * 2 + half) * VQ_TOP;
+#pragma unroll
+    for (int t = 0; t < VQ_TOP; ++t) { g.part_val[p + t] = bv[j][t]; g.part_idx[p + t] = bi[j][t]; }
+  }
+}
+
 }  // namespace g3
 
 // called by ctclip_gemm_bf16 (gemm.hip): k-major x k-major, K % 32 == 0, plain (non-accumulating) output
@@ -308,5 +439,23 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
     }
     hipLaunchKernelGGL((gemm3_kernel<128, 3, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, st, g);
   }
+  return (int)hipGetLastError();
+}
+
+// called by ctclip_vq_topk (gemm.hip): codes M % 256 == 0, K % 32 == 0; part_val / part_idx are [N][16]
+int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
+                           long ldb, hipStream_t st) {
+  using namespace g3;
+  VqArgs g{};
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+  g.tiles_m = M / BM; g.part_val = part_val; g.part_idx = part_idx;
+  const size_t lds = (size_t)4 * 2 * SUB;          // 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)vq_topk3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(vq_topk3_kernel, dim3((N + 255) / 256), dim3(512), lds, st, g);
   return (int)hipGetLastError();
 }

@@ -285,10 +285,13 @@ class PegFn(Function):
         ctx.geom = (b, t, h, w, d, int(residual))
         ctx.params = (weight, bias)
         ctx.mark_non_differentiable(y16)
+        ctx.set_materialize_grads(False)      # or autograd zero-fills a [tokens, d] bf16 "gradient" of y16 for every backward
         return y, y16
 
     @staticmethod
     def backward(ctx, dy, _dy16):
+        if dy is None:
+            return None, None, None, None, None
         xc, w27 = ctx.saved_tensors
         b, t, h, w, d, residual = ctx.geom
         dyc = _c(dy)

@@ -224,6 +224,35 @@ def test_gemm_argmax_partial_and_exact_select(hip):
     assert float((idx2 == ref).float().mean()) >= 0.995
 
 
+@pytest.mark.parametrize("C_,T,K", [(512, 600, 64), (1024, 256, 512), (256, 40, 32)])
+def test_vq_topk_whole_code_tiles(hip, C_, T, K):
+    """ctclip_vq_topk when the codebook is whole 256-code tiles (the CT-ViT's 8192 x 512): the 256 x 256 LDS-DMA sweep
+    in csrc/gemm3.hip.  Ragged token tiles, more and fewer K-steps than ring stages; the 16 candidates must contain the
+    bf16 arg-max and the exact f32 re-ranking must return the true nearest code, planted near-ties included."""
+    Ef = torch.nn.functional.normalize(rnd(C_, K, seed=7), dim=-1).contiguous()
+    Xraw = (rnd(T, K, seed=8) * 3).contiguous()
+    for t, (c1, c2) in enumerate([(5, 70), (200, 201), (C_ - 1, 3)]):
+        Xraw[t] = (Ef[c1] + Ef[c2]) * 2 + 2e-4 * (Ef[c2] - Ef[c1])
+    inv = 1.0 / Xraw.norm(dim=-1)
+    E, X = bf(Ef), bf(Xraw * inv[:, None])
+    pv = torch.full((T, 16), float("nan"), device=DEV)
+    pi = torch.full((T, 16), -1, device=DEV, dtype=torch.int32)
+    hip.vq_topk(E, X, pv, pi, C_, T, K, K, K)
+    assert bool(((pi >= 0) & (pi < C_)).all()), "every candidate slot holds a code (256-code tiles fill all 16)"
+    assert bool((pi.sort(dim=1).values.diff(dim=1) != 0).all()), "candidates of a token are distinct codes"
+    s16 = X.float() @ E.float().t()
+    check("candidate scores", pv, s16.gather(1, pi.long()), 1e-5)
+    got16 = pv.max(dim=1).values
+    assert float((s16.max(dim=1).values - got16).abs().max()) <= 1e-5, "candidates must contain the bf16 arg-max"
+    idx = torch.empty(T, dtype=torch.long, device=DEV)
+    quant = torch.empty(T, K, device=DEV)
+    hip.vq_select(pv, pi, 16, Xraw, inv, Ef, idx, quant, T, K, 2.0 ** -7)
+    exact = (Xraw * inv[:, None]) @ Ef.t()
+    gap = exact.max(dim=1).values - exact.gather(1, idx[:, None])[:, 0]
+    assert float(gap.max()) <= 2e-7 and torch.equal(idx[:3].cpu(), torch.tensor([70, 201, 3]))
+    assert float((idx == exact.argmax(dim=1)).float().mean()) >= 0.995
+
+
 # ---------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("rows,dim,with_beta", [(37, 512, False), (130, 768, True), (9, 56, True), (5, 4000, True)])
 def test_layernorm_fwd_bwd(hip, rows, dim, with_beta):
