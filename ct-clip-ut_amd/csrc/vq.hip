@@ -100,6 +100,9 @@ __global__ __launch_bounds__(256) void vq_select_kernel(const float* __restrict_
       if (d > best || (d == best && c < besti)) { best = d; besti = c; }
     }
   }
+  // a token whose scores are all NaN (or that has no candidate at all) has nothing to compare: give it code 0 rather
+  // than let the empty-slot marker be used as a row number below and by the EMA accumulation
+  if (besti == 0x7fffffff) besti = 0;
   if (lane == 0) idx_out[tok] = besti;
   if (quant) {
     const float4* e = (const float4*)(embed + (long)besti * dim);

@@ -251,6 +251,13 @@ def test_vq_topk_whole_code_tiles(hip, C_, T, K):
     gap = exact.max(dim=1).values - exact.gather(1, idx[:, None])[:, 0]
     assert float(gap.max()) <= 2e-7 and torch.equal(idx[:3].cpu(), torch.tensor([70, 201, 3]))
     assert float((idx == exact.argmax(dim=1)).float().mean()) >= 0.995
+    # a NaN token (a broken upstream weight) has no comparable score: it must come out as code 0, not as the empty-slot
+    # marker used as a row number
+    Xn = X.clone()
+    Xn[T - 1] = float("nan")
+    hip.vq_topk(E, Xn, pv, pi, C_, T, K, K, K)
+    hip.vq_select(pv, pi, 16, Xraw, inv, Ef, idx, quant, T, K, 2.0 ** -7)
+    assert int(idx[T - 1]) == 0 and bool(((idx >= 0) & (idx < C_)).all())
 
 
 # ---------------------------------------------------------------------------------------------- norms
