@@ -239,7 +239,7 @@ def main():
                        "negatives": "local" if args.local_negatives or world == 1 else "global (all-gather)",
                        "parallelism": f"dp{world}", "peak_hbm_gib": round(peak_mem, 1), "final_loss": float(loss)},
             "roofline": {"kernel": "ctclip_gemm_bf16 family (gemm3_kernel 256x256x32 four-stage LDS-DMA ring for the k-major products, "
-                                   "gemm2_kernel 256x128x64 for weight gradients, gemm_bf16_kernel 128x128 for small grids)", "bound": "mfma", "achieved": gemm_tflops,
+                                   "gemm4_kernel, the same tile with transposed operands, for weight gradients, gemm2/gemm_bf16 kernels for small grids)", "bound": "mfma", "achieved": gemm_tflops,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_BF16_TFLOPS,
                          "traffic": None, "launches_per_step": timing["launches"] / args.steps,
                          "gemm_ms_per_step": timing["total_ms"] / args.steps,
