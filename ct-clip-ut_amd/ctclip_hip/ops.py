@@ -421,9 +421,12 @@ class AttentionFn(Function):
             wgrad(dq, n1, inner, dim, M, out=gwq)
             dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, out_dtype=BF16, wT16=sh.get("wkvT"))
             wgrad(dkv, xb, 2 * inner, dim, M, out=gwkv)
-            dx16 = torch.empty(M, dim, dtype=BF16, device=dev)
+            # x came from a PEG (it handed us its bf16 copy): this gradient goes back into the PEG backward, which reads
+            # f32 only, so a bf16 mirror of it would be a gigabyte written for nobody
+            dx16 = torch.empty(M, dim, dtype=BF16, device=dev) if aux.get("x16") is None else None
             hip.layernorm_bwd_bf16(dn1, x2, gamma, mean, rstd, dy2 if residual else None, dxkv, dx, dx16, gg, None, M, dim)
-            return (_tag16(dx.reshape(nseq, n, dim), dx16), _ret(gg, d6), _ret(gwq, d3), _ret(gwkv, d4), _ret(gqs, d1), _ret(gks, d2),
+            dxr = dx.reshape(nseq, n, dim)
+            return (_tag16(dxr, dx16) if dx16 is not None else dxr, _ret(gg, d6), _ret(gwq, d3), _ret(gwkv, d4), _ret(gqs, d1), _ret(gks, d2),
                     _ret(gwo, d5), dbias, None, None, None)
         dwout = wgrad(dyb, o, dim, inner, M)
         dqs = torch.zeros(dp, dtype=F32, device=dev)
