@@ -160,12 +160,18 @@ def wgrad(dy16, x16, n_feat, k_feat, tokens, out=None):
     return on_side_stream(lambda: _wgrad_now(dy16, x16, n_feat, k_feat, tokens, out), dy16, x16, out)
 
 def colsum(x2d, out=None):
-    """out[c] (+)= sum_r x[r, c]  (bias gradients); x f32 or bf16."""
+    """out[c] (+)= sum_r x[r, c]  (bias gradients); x f32 or bf16.  With `out` given (a `.grad` slot) the sum is
+    fire-and-forget on the weight-gradient stream, like wgrad()."""
     rows, cols = x2d.shape
     if out is None:
         out = torch.zeros(cols, dtype=F32, device=x2d.device)
-    hip.colsum_accum(x2d, int(x2d.dtype == BF16), rows, cols, x2d.stride(0), out)
-    return out
+        hip.colsum_accum(x2d, int(x2d.dtype == BF16), rows, cols, x2d.stride(0), out)
+        return out
+
+    def run():
+        hip.colsum_accum(x2d, int(x2d.dtype == BF16), rows, cols, x2d.stride(0), out)
+        return out
+    return on_side_stream(run, x2d, out)
 
 
 def dgrad(dy16, w16, tokens, n_feat, k_feat, *, out_dtype=F32, resid=None, wT16=None):
