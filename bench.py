@@ -6,8 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 A step = CTClipTrainer.train_step on one synthetic batch already resident in HBM: zero_grad, CT-ViT + BERT forward,
-similarity matrix + symmetric InfoNCE, backward, RCCL gradient all-reduce (N>1), fused clip(0.5)+Adam; the loss stays on
-the device and is read once after the timed region.
+similarity matrix + symmetric InfoNCE, backward, RCCL gradient all-reduce (N>1), fused clip(0.5)+Adam, loss.item().
 Workload (BASELINE configs[1]): CT-ViT base (dim 512, 4+4 layers, 8x32 heads, codebook 8192) + BERT-base-shaped text
 encoder (12x768, the shape of CXR-BERT), 480x480x240 bf16 volumes, 128-token reports, random-init weights.
 Rank 0 prints ONE json line (see README / DESIGN.md "Measurement").
@@ -194,10 +193,9 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.train_step(batch, return_tensor=True)      # the loss stays on the device: no host sync between steps
+        loss = trainer.train_step(batch)          # returns the python float the reference's train_step returns (.item())
     sync()
     dt = time.perf_counter() - t0
-    loss = float(loss)
     def gemm_timing():
         timed = hip.stop_timing()
         return {k: sum(timed[n][k] for n in ("ctclip_gemm_bf16", "ctclip_gemm_bf16_geglu", "ctclip_gemm_bf16_geglu_bwd"))
