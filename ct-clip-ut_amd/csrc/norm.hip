@@ -8,15 +8,25 @@ namespace {
 
 constexpr int LN_MAXV = 16;  // float4 per lane -> dim <= 64*4*16 = 4096
 
+// Token re-ordering folded into the row addressing (reference ctvit.py:96,99,101: the rearranges between the spatial and
+// the temporal transformer).  Rows seen as [B][A][C]; the other side of the kernel holds them as [B][C][A].  A == 0: none.
+__device__ __forceinline__ long swapped_row(int row, int a_ext, int c_ext) {
+  if (a_ext <= 0) return row;
+  const int ac = a_ext * c_ext, b = row / ac, rem = row - b * ac, a = rem / c_ext, c = rem - a * c_ext;
+  return (long)b * ac + (long)c * a_ext + a;
+}
+
 // reference src/utils/attention.py:27-34,46 ; src/utils/ctvit.py:49,51 ; transformers BertLayerNorm
 template <int LN_NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ y16,
                                                             float* __restrict__ y32, float* __restrict__ mean,
-                                                            float* __restrict__ rstd, int rows, int dim, float eps) {
+                                                            float* __restrict__ rstd, int rows, int dim, float eps,
+                                                            int swap_a, int swap_c) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const long orow = swapped_row(row, swap_a, swap_c);   // where the normalised row goes (statistics stay in input order)
   const int nv = dim >> 2;  // float4 count
   const float4* xr = (const float4*)(x + (long)row * dim);
   float4 v[LN_NV];
@@ -56,12 +66,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       o.y = (v[i].y - mu) * rs * g.y + b.y;
       o.z = (v[i].z - mu) * rs * g.z + b.z;
       o.w = (v[i].w - mu) * rs * g.w + b.w;
-      if (y32) ((float4*)(y32 + (long)row * dim))[c] = o;
+      if (y32) ((float4*)(y32 + orow * dim))[c] = o;
       if (y16) {
         uint2 p;
         p.x = pack_bf16x2(o.x, o.y);
         p.y = pack_bf16x2(o.z, o.w);
-        ((uint2*)(y16 + (long)row * dim))[c] = p;
+        ((uint2*)(y16 + orow * dim))[c] = p;
       }
     }
   }
@@ -83,7 +93,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             const bf16_t* __restrict__ dres2,
                                                             float* __restrict__ dx, bf16_t* __restrict__ dx16,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rows, int dim) {
+                                                            int rows, int dim, int swap_a, int swap_c) {
   extern __shared__ __attribute__((aligned(16))) float lnred[];   // [2][dim]
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -100,8 +110,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
   for (int row = wave_global; row < rows; row += nwaves) {
     const float mu = mean[row], rs = rstd[row];
     const float4* xr = (const float4*)(x + (long)row * dim);
-    const float4* dr = (const float4*)((const float*)dy_any + (long)row * dim);
-    const bf16_t* dr16 = (const bf16_t*)dy_any + (long)row * dim;
+    const long yrow = swapped_row(row, swap_a, swap_c);           // dy lives in the forward's OUTPUT order
+    const float4* dr = (const float4*)((const float*)dy_any + yrow * dim);
+    const bf16_t* dr16 = (const bf16_t*)dy_any + yrow * dim;
     float4 xh[LN_NV], gg[LN_NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -269,7 +280,7 @@ int ctclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
   if ((dim & 3) || dim > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
 #define LN_FWD(NV)                                                                                              \
   hipLaunchKernelGGL(layernorm_fwd_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, \
-                     beta, (bf16_t*)y_bf16, y_f32, mean, rstd, rows, dim, eps)
+                     beta, (bf16_t*)y_bf16, y_f32, mean, rstd, rows, dim, eps, 0, 0)
   const int nv = (dim / 4 + 63) / 64;
   if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 3) LN_FWD(3); else if (nv <= 4) LN_FWD(4); else LN_FWD(16);
 #undef LN_FWD
@@ -286,7 +297,38 @@ int ctclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
   const size_t lnlds = (size_t)2 * dim * sizeof(float);
 #define LN_BWD(NV)                                                                                                      \
   hipLaunchKernelGGL((layernorm_bwd_kernel<NV, false>), dim3(blocks), dim3(256), lnlds, (hipStream_t)stream, (const void*)dy, x, \
-                     gamma, mean, rstd, dres, (const bf16_t*)nullptr, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim)
+                     gamma, mean, rstd, dres, (const bf16_t*)nullptr, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim, 0, 0)
+  const int nv = (dim / 4 + 63) / 64;
+  if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(16);
+#undef LN_BWD
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_layernorm_swap_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, float* mean, float* rstd,
+                              int rows, int dim, float eps, int A, int C, void* stream) {
+  if (rows <= 0) return 0;
+  if ((dim & 3) || dim > 64 * 4 * LN_MAXV || A <= 0 || C <= 0 || rows % (A * C)) return (int)hipErrorInvalidValue;
+#define LN_FWD(NV)                                                                                              \
+  hipLaunchKernelGGL(layernorm_fwd_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, \
+                     beta, (bf16_t*)nullptr, y_f32, mean, rstd, rows, dim, eps, A, C)
+  const int nv = (dim / 4 + 63) / 64;
+  if (nv <= 1) LN_FWD(1); else if (nv <= 2) LN_FWD(2); else if (nv <= 3) LN_FWD(3); else if (nv <= 4) LN_FWD(4); else LN_FWD(16);
+#undef LN_FWD
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_layernorm_swap_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              float* dx, void* dx_bf16, float* dgamma, float* dbeta, int rows, int dim, int A, int C,
+                              void* stream) {
+  if (rows <= 0) return 0;
+  if ((dim & 3) || dim > 64 * 4 * LN_MAXV || A <= 0 || C <= 0 || rows % (A * C)) return (int)hipErrorInvalidValue;
+  int blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  const size_t lnlds = (size_t)2 * dim * sizeof(float);
+#define LN_BWD(NV)                                                                                                      \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NV, false>), dim3(blocks), dim3(256), lnlds, (hipStream_t)stream, (const void*)dy, x, \
+                     gamma, mean, rstd, (const float*)nullptr, (const bf16_t*)nullptr, dx, (bf16_t*)dx_bf16, dgamma, dbeta,   \
+                     rows, dim, A, C)
   const int nv = (dim / 4 + 63) / 64;
   if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(16);
 #undef LN_BWD
@@ -303,7 +345,7 @@ int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* 
   const size_t lnlds = (size_t)2 * dim * sizeof(float);
 #define LN_BWD16(NV)                                                                                                    \
   hipLaunchKernelGGL((layernorm_bwd_kernel<NV, true>), dim3(blocks), dim3(256), lnlds, (hipStream_t)stream, dy_bf16, x, gamma, \
-                     mean, rstd, dres, (const bf16_t*)dres2_bf16, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim)
+                     mean, rstd, dres, (const bf16_t*)dres2_bf16, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim, 0, 0)
   const int nv = (dim / 4 + 63) / 64;
   if (nv <= 1) LN_BWD16(1); else if (nv <= 2) LN_BWD16(2); else if (nv <= 3) LN_BWD16(3); else if (nv <= 4) LN_BWD16(4); else LN_BWD16(16);
 #undef LN_BWD16

@@ -250,26 +250,47 @@ def _get16(t32):
 # LayerNorm as a module-level op (Transformer.norm_out, patch-embed tail)
 # ---------------------------------------------------------------------------------------------------
 class LayerNormFn(Function):
+    """LayerNorm over the last dimension.  swap = (A, C): the rows of x are [B][A][C] and the result comes back as
+    [B, C, A, d] -- the CT-ViT's token re-ordering between its spatial and temporal transformers (ctvit.py:96,99,101)
+    done by the kernel's row addressing instead of a separate permutation pass over the stream."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, swap=None):
         shape = x.shape
         x2 = _c(x).reshape(-1, shape[-1])
-        _, y, mean, rstd = layernorm(x2, gamma, beta, eps, want16=False, want32=True)
+        if swap is None:
+            _, y, mean, rstd = layernorm(x2, gamma, beta, eps, want16=False, want32=True)
+            y = y.reshape(shape)
+        else:
+            A, C = int(swap[0]), int(swap[1])
+            rows, dim = x2.shape
+            if rows % (A * C):
+                raise ValueError(f"LayerNormFn: {rows} rows are not a whole number of [{A}][{C}] blocks")
+            y = torch.empty(rows // (A * C), C, A, dim, dtype=F32, device=x2.device)
+            mean = torch.empty(rows, dtype=F32, device=x2.device)
+            rstd = torch.empty(rows, dtype=F32, device=x2.device)
+            hip.layernorm_swap_fwd(x2, gamma.detach(), None if beta is None else beta.detach(), y, mean, rstd, rows, dim,
+                                   float(eps), A, C)
         ctx.save_for_backward(x2, mean, rstd)
         ctx.params = (gamma, beta)
-        return y.reshape(shape)
+        ctx.swap, ctx.xshape = swap, shape
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         x2, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.params
-        dy2 = _c(dy).reshape(x2.shape)
         dx = torch.empty_like(x2)
         dx16 = torch.empty(x2.shape, dtype=BF16, device=x2.device)
         dg, dg_d = grad_slot(gamma)
         db, db_d = grad_slot(beta) if beta is not None else (None, True)
-        hip.layernorm_bwd(dy2, x2, gamma.detach(), mean, rstd, None, dx, dx16, dg, db, x2.shape[0], x2.shape[1])
-        return _tag16(dx.reshape(dy.shape), dx16), _ret(dg, dg_d), _ret(db, db_d), None
+        if ctx.swap is None:
+            hip.layernorm_bwd(_c(dy).reshape(x2.shape), x2, gamma.detach(), mean, rstd, None, dx, dx16, dg, db, x2.shape[0],
+                              x2.shape[1])
+        else:
+            hip.layernorm_swap_bwd(_c(dy), x2, gamma.detach(), mean, rstd, dx, dx16, dg, db, x2.shape[0], x2.shape[1],
+                                   int(ctx.swap[0]), int(ctx.swap[1]))
+        return _tag16(dx.reshape(ctx.xshape), dx16), _ret(dg, dg_d), _ret(db, db_d), None, None
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -49,6 +49,11 @@ class LayerNorm(nn.Module):
         _need_cuda(x, "LayerNorm")
         return ops.LayerNormFn.apply(x.to(F32), self.gamma, None, 1e-5)
 
+    def forward_swapped(self, x, a_ext, c_ext):
+        """The same normalisation of rows laid out [B][a_ext][c_ext], returned as [B, c_ext, a_ext, d]."""
+        _need_cuda(x, "LayerNorm")
+        return ops.LayerNormFn.apply(x.to(F32), self.gamma, None, 1e-5, (int(a_ext), int(c_ext)))
+
 
 class GEGLU(nn.Module):
     """Placeholder that keeps the reference's Sequential indices (attention.py:38-41); the gate is fused
@@ -308,7 +313,10 @@ class Transformer(nn.Module):
         self.norm_out = LayerNorm(dim)
 
     def forward(self, x, video_shape: Tuple[int, int, int, int] = None, attn_bias=None, context=None,
-                self_attn_mask=None, cross_attn_context_mask=None):
+                self_attn_mask=None, cross_attn_context_mask=None, out_swap=None):
+        """Reference signature (attention.py:313-336) plus `out_swap=(A, C)`: the rows of the result, [B][A][C] as this
+        transformer sees them, are returned as [B, C, A, d] -- the re-ordering CTViT.encode applies next (ctvit.py:96,
+        101), written by the final LayerNorm itself."""
         _need_cuda(x, "Transformer")
         if exists(context) or exists(self_attn_mask) or exists(cross_attn_context_mask):
             raise NotImplementedError("context / masks are GenerateCT-only branches")
@@ -331,4 +339,9 @@ class Transformer(nn.Module):
             else:
                 x, _w = self_attn.forward(x, attn_bias=attn_bias, residual=True, x16=x16)
             x = ff(x) + x if _hooked(ff) else ff.forward(x, residual=True)
-        return self.norm_out(x)
+        if out_swap is None:
+            return self.norm_out(x)
+        if _hooked(self.norm_out):                   # a hook wants the reference's output: normalise, then re-order
+            y = self.norm_out(x)
+            return ops.SwapMiddleFn.apply(y.reshape(-1, int(out_swap[0]), int(out_swap[1]), y.shape[-1]))
+        return self.norm_out.forward_swapped(x, out_swap[0], out_swap[1])

@@ -4,6 +4,7 @@
 Forward = tubelet patch-embed kernel chain -> 4 spatial transformer layers (576-token sequences, relative
 position bias) -> 4 temporal layers (24-token sequences) -> cosine-sim VQ; all HIP (see ctclip_hip.ops).
 """
+import os
 from pathlib import Path
 
 import torch
@@ -12,7 +13,7 @@ from einops.layers.torch import Rearrange
 
 from ctclip_hip import ops
 from ctclip_hip.vq import VectorQuantize
-from utils.attention import Attention, Transformer, ContinuousPositionBias  # noqa: F401
+from utils.attention import Attention, Transformer, ContinuousPositionBias, _hooked  # noqa: F401
 
 F32 = torch.float32
 BF16 = torch.bfloat16
@@ -86,10 +87,17 @@ class CTViT(nn.Module):
         video_shape = (b, t, h, w)
         attn_bias = self.spatial_rel_pos_bias.lookup(h, w, device=tokens.device)
         x = tokens.reshape(b * t, h * w, d)
-        x = self.enc_spatial_transformer(x, attn_bias=attn_bias, video_shape=video_shape)
-        x = ops.SwapMiddleFn.apply(x.reshape(b, t, h * w, d))                    # (b t)(h w) -> (b h w) t
-        x = self.enc_temporal_transformer(x.reshape(b * h * w, t, d), video_shape=video_shape)
-        x = ops.SwapMiddleFn.apply(x.reshape(b, h * w, t, d))                    # back to b t (h w)
+        sp, tp = self.enc_spatial_transformer, self.enc_temporal_transformer
+        if _hooked(sp) or _hooked(tp) or os.environ.get("CTCLIP_NO_LN_SWAP"):
+            # someone watches a transformer's output: keep the reference's layouts and re-order in separate passes
+            x = sp(x, attn_bias=attn_bias, video_shape=video_shape)
+            x = ops.SwapMiddleFn.apply(x.reshape(b, t, h * w, d))                # (b t)(h w) -> (b h w) t
+            x = tp(x.reshape(b * h * w, t, d), video_shape=video_shape)
+            x = ops.SwapMiddleFn.apply(x.reshape(b, h * w, t, d))                # back to b t (h w)
+            return x.reshape(b, t, h, w, d)
+        # the two re-orderings (ctvit.py:96,101) are written by each transformer's final LayerNorm
+        x = sp(x, attn_bias=attn_bias, video_shape=video_shape, out_swap=(t, h * w))          # -> [b, h*w, t, d]
+        x = tp(x.reshape(b * h * w, t, d), video_shape=video_shape, out_swap=(h * w, t))      # -> [b, t, h*w, d]
         return x.reshape(b, t, h, w, d)
 
     def forward(self, image, return_only_codebook_ids=False):

@@ -53,6 +53,14 @@ int ctclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
 /* same with the LN-path gradient in bf16 (the output of a bf16 data-gradient GEMM) and an optional second, bf16,
  * residual-path term: dx = dres + dres2 + LN'(dy).  (the K/V projection of attention.py:138 reads the un-normalised x, so
  * its data gradient by-passes LN'.) */
+/* The same LayerNorm with the token re-ordering between the CT-ViT's spatial and temporal transformers folded into its
+ * row addressing (ctvit.py:96,99,101: `(b t)(h w) d -> (b h w) t d` and back; Transformer.norm_out, attention.py:311,336):
+ * x rows are [B][A][C], y rows (and the backward's dy rows) are [B][C][A].  mean / rstd / dx stay in x order. */
+int ctclip_layernorm_swap_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, float* mean, float* rstd,
+                              int rows, int dim, float eps, int A, int C, void* stream);
+int ctclip_layernorm_swap_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              float* dx, void* dx_bf16, float* dgamma, float* dbeta, int rows, int dim, int A, int C,
+                              void* stream);
 int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* dres, const void* dres2_bf16, float* dx, void* dx_bf16, float* dgamma,
                               float* dbeta, int rows, int dim, void* stream);

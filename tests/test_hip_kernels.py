@@ -261,6 +261,30 @@ def test_vq_topk_whole_code_tiles(hip, C_, T, K):
 
 
 # ---------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,A,C,dim", [(2, 3, 5, 512), (1, 24, 7, 64), (3, 4, 4, 56)])
+def test_layernorm_with_token_reordering(hip, B, A, C, dim):
+    """ctclip_layernorm_swap_fwd / _bwd: Transformer.norm_out (attention.py:311,336) writing its rows [B][A][C] straight
+    into the [B][C][A] order of the rearrange that follows it in CTViT.encode (ctvit.py:96,101), and the backward reading
+    dy in that order."""
+    rows = B * A * C
+    x = (rnd(rows, dim, seed=31) * 2 + 0.5).requires_grad_(True)
+    gm = (1 + 0.3 * rnd(dim, seed=32)).requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x, (dim,), gm, None, 1e-5).reshape(B, A, C, dim).permute(0, 2, 1, 3).contiguous()
+    y = torch.empty(B, C, A, dim, device=DEV)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    hip.layernorm_swap_fwd(x.detach(), gm.detach(), None, y, mean, rstd, rows, dim, 1e-5, A, C)
+    check("swapped ln y", y, ref, 1e-5)
+    dy = rnd(B, C, A, dim, seed=33)
+    ref.backward(dy)
+    dx = torch.empty(rows, dim, device=DEV)
+    dx16 = torch.empty(rows, dim, device=DEV, dtype=torch.bfloat16)
+    dg = torch.zeros(dim, device=DEV)
+    hip.layernorm_swap_bwd(dy, x.detach(), gm.detach(), mean, rstd, dx, dx16, dg, None, rows, dim, A, C)
+    check("swapped ln dx", dx, x.grad, 1e-4)
+    check("swapped ln dx16", dx16, x.grad, 1e-2)
+    check("swapped ln dgamma", dg, gm.grad, 1e-4)
+
+
 @pytest.mark.parametrize("rows,dim,with_beta", [(37, 512, False), (130, 768, True), (9, 56, True), (5, 4000, True)])
 def test_layernorm_fwd_bwd(hip, rows, dim, with_beta):
     x = (rnd(rows, dim, seed=9) * 2 + 0.5).requires_grad_(True)
