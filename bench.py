@@ -29,7 +29,8 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH
 VIT = dict(dim=512, codebook_size=8192, image_size=480, patch_size=20, temporal_patch_size=10, spatial_depth=4,
            temporal_depth=4, dim_head=32, heads=8)                      # reference src/train_ctclip.py:19-29
 TEXT = dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, vocab_size=30522,
-            max_position_embeddings=512, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+            max_position_embeddings=512, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)   # BertConfig / CXR-BERT defaults: the
+                                                                      # reference trains with them on (model.train())
 
 
 def build_model(vit_cfg, text_cfg, dim_latent=512):
@@ -234,7 +235,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("debug-small" if args.small else
                                     "BASELINE configs[1]: CT-ViT base (512d, 4+4 layers, 8x32 heads, cb 8192) + BERT-base-shape "
-                                    "text encoder, 480x480x240 bf16 volumes, 128-token reports, full train_step"),
+                                    "text encoder, 480x480x240 bf16 volumes, 128-token reports, text dropout 0.1, full train_step"),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "text_len": args.text_len,
                        "negatives": "local" if args.local_negatives or world == 1 else "global (all-gather)",
                        "parallelism": f"dp{world}", "peak_hbm_gib": round(peak_mem, 1), "final_loss": float(loss)},

@@ -66,6 +66,26 @@ __device__ __forceinline__ void apply_scores(f32x16& s, const float (&add)[16], 
   }
 }
 
+// attention-probability dropout (transformers BertSelfAttention: `attention_probs = self.dropout(attention_probs)`): the
+// caller draws the keep flags, the kernels only apply them, so forward and backward see the same mask by construction.
+// keep[reg] = drop_scale where the flag of (query row, key key_base + acc_row(reg)) is set, else 0  ("lane = query").
+__device__ __forceinline__ void load_keep(float (&keep)[16], const AttnArgs& a, int head, int seq, int qrow_c, int key_base,
+                                          int half) {
+  const uint8_t* row = a.drop + (((long)seq * a.heads + head) * a.n + qrow_c) * a.n;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const int k0 = key_base + 8 * g4 + 4 * half;
+    if (((a.n & 3) == 0) && k0 + 3 < a.n) {
+      const uint32_t w = *(const uint32_t*)(row + k0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) keep[4 * g4 + i] = ((w >> (8 * i)) & 0xffu) ? a.drop_scale : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) keep[4 * g4 + i] = (k0 + i < a.n && row[k0 + i]) ? a.drop_scale : 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -137,8 +157,14 @@ __global__ __launch_bounds__(D == 32 ? 576 : 256) void attn_fwd_kernel(AttnArgs 
       psum += p;
     }
     psum += __shfl_xor(psum, 32, 64);
-    l = l * alpha + psum;
+    l = l * alpha + psum;                                  // the softmax normaliser is over ALL keys, dropped or not
     m = mnew;
+    if (a.drop) {
+      float keep[16];
+      load_keep(keep, a, head, seq, qrow_c, kt, half);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] *= keep[i];
+    }
     const bf16x8 p0 = acc_frag(s, 0), p1 = acc_frag(s, 1);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -233,6 +259,12 @@ __global__ __launch_bounds__(D == 32 ? 384 : 256) void attn_bwd_dq_kernel(AttnAr
       if (kt + 32 < a.n_pad) load_v(vf, kt + 32);          // re-load in place right after the last use
       apply_scores(s, add, a, kt, half);
       if (kt + 32 < a.n_pad) load_addend(add, a, head, seq, qrow_c, kt + 32, half);
+      if (a.drop) {                                         // d(P) reaches only the kept entries, scaled like them
+        float keep[16];
+        load_keep(keep, a, head, seq, qrow_c, kt, half);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dp[i] *= keep[i];
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const float p = valid ? __expf(s[i] - lse) : 0.f;  // -inf scores -> 0
@@ -339,6 +371,7 @@ __global__ __launch_bounds__(D == 32 ? 384 : 256) void attn_bwd_dkv_kernel(AttnA
   }
   const float mval = (a.mask && valid) ? a.mask[(long)seq * a.n + key] : 0.f;
   const float* bcol = a.bias ? a.bias + (long)head * a.n * a.n + key_c : nullptr;
+  const uint8_t* drow = a.drop ? a.drop + ((long)seq * a.heads + head) * a.n * a.n + key_c : nullptr;
 
   f32x16 dkacc[DT], dvacc[DT];
 #pragma unroll
@@ -375,8 +408,10 @@ __global__ __launch_bounds__(D == 32 ? 384 : 256) void attn_bwd_dkv_kernel(AttnA
       for (int i = 0; i < 4; ++i) {
         const float v = s[4 * g4 + i] * a.scale + mval + bcur[4 * g4 + i];
         const float p = valid ? __expf(v - ls[i]) : 0.f;
-        s[4 * g4 + i] = p;
-        dp[4 * g4 + i] = p * (dp[4 * g4 + i] - de[i]);
+        float keep = 1.f;                                   // dropout flag of (query qb + i, this lane's key)
+        if (a.drop) keep = (qb + i < a.n && drow[(long)(qb + i) * a.n]) ? a.drop_scale : 0.f;
+        s[4 * g4 + i] = p * keep;                           // what multiplied V in the forward
+        dp[4 * g4 + i] = p * (dp[4 * g4 + i] * keep - de[i]);
       }
     }
 #pragma unroll
@@ -591,10 +626,11 @@ inline int heads_per_block(int n_pad, int nw, int heads, int max_waves, size_t l
 
 extern "C" {
 
-int ctclip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
-                    const float* mask, int nseq, int n, int heads, int dhead, long ldq, long ldk, long ldv, long ldo,
-                    float scale, void* stream) {
+int ctclip_attn_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
+                            const float* mask, const uint8_t* keep, float keep_scale, int nseq, int n, int heads, int dhead,
+                            long ldq, long ldk, long ldv, long ldo, float scale, void* stream) {
   AttnArgs a{};
+  a.drop = keep; a.drop_scale = keep_scale;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.o = (bf16_t*)o; a.lse = lse;
   a.bias = bias; a.mask = mask; a.nseq = nseq; a.n = n; a.n_pad = (n + 31) / 32 * 32; a.heads = heads;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
@@ -620,12 +656,21 @@ int ctclip_attn_fwd(const void* q, const void* k, const void* v, void* o, float*
   CTCLIP_CHECK_LAUNCH();
 }
 
-int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
-                    float* delta, void* dq, void* dk, void* dv, const float* bias, const float* mask,
-                    float* dbias_dense, const uint16_t* relidx, float* dbias_table, int table_size, int grid_h, int grid_w,
-                    int nseq, int n, int heads, int dhead, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq,
-                    long lddk, long lddv, float scale, void* stream) {
+int ctclip_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
+                    const float* mask, int nseq, int n, int heads, int dhead, long ldq, long ldk, long ldv, long ldo,
+                    float scale, void* stream) {
+  return ctclip_attn_fwd_dropout(q, k, v, o, lse, bias, mask, nullptr, 1.0f, nseq, n, heads, dhead, ldq, ldk, ldv, ldo, scale,
+                                 stream);
+}
+
+int ctclip_attn_bwd_dropout(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
+                            float* delta, void* dq, void* dk, void* dv, const float* bias, const float* mask,
+                            const uint8_t* keep, float keep_scale, float* dbias_dense, const uint16_t* relidx,
+                            float* dbias_table, int table_size, int grid_h, int grid_w, int nseq, int n, int heads, int dhead,
+                            long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale,
+                            void* stream) {
   AttnArgs a{};
+  a.drop = keep; a.drop_scale = keep_scale;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.oin = (const bf16_t*)o;
   a.dO = (const bf16_t*)dO; a.lse = (float*)lse; a.delta = delta; a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk;
   a.dv = (bf16_t*)dv; a.bias = bias; a.mask = mask; a.dbias_dense = dbias_dense; a.relidx = relidx;
@@ -642,7 +687,7 @@ int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, 
     if (e >= 0) return e;
   }
   static const bool no_small = getenv("CTCLIP_ATTN_NO_SMALL") != nullptr;
-  if (dhead == 32 && n <= 32 && !a.dbias_dense && !a.dbias_table && !no_small) {
+  if (dhead == 32 && n <= 32 && !a.dbias_dense && !a.dbias_table && !a.drop && !no_small) {
     const long items = (long)nseq * heads;
     const int wpb = 8;
     hipLaunchKernelGGL(attn_small_bwd_kernel, dim3((unsigned)((items + wpb - 1) / wpb)), dim3(wpb * 64),
@@ -676,6 +721,16 @@ int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, 
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid2, block2, lds2, st, a2);
   }
   CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
+                    float* delta, void* dq, void* dk, void* dv, const float* bias, const float* mask,
+                    float* dbias_dense, const uint16_t* relidx, float* dbias_table, int table_size, int grid_h, int grid_w,
+                    int nseq, int n, int heads, int dhead, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq,
+                    long lddk, long lddv, float scale, void* stream) {
+  return ctclip_attn_bwd_dropout(q, k, v, o, dO, lse, delta, dq, dk, dv, bias, mask, nullptr, 1.0f, dbias_dense, relidx,
+                                 dbias_table, table_size, grid_h, grid_w, nseq, n, heads, dhead, ldq, ldk, ldv, ldo, lddo,
+                                 lddq, lddk, lddv, scale, stream);
 }
 
 int ctclip_attn_probs(const void* q, const void* k, const float* lse, const float* bias, const float* mask,

@@ -632,7 +632,7 @@ int cu_count() {
 }
 
 bool sp_shape_ok(const AttnArgs& a, int dhead) {
-  if (!sp_enabled() || dhead != 32 || a.mask) return false;
+  if (!sp_enabled() || dhead != 32 || a.mask || a.drop) return false;
   if (a.n % 32) return false;
   const int T = a.n / 32;
   return T >= 4 && T <= 3 * kMaxWaves;

@@ -21,6 +21,8 @@ struct CtclipAttnArgs {
   long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
   int nseq, n, n_pad, heads;
   float scale;
+  const uint8_t* drop;       // [nseq, H, n, n] keep flags (1 = keep) of attention-probability dropout, or null
+  float drop_scale;          // 1 / (1 - p): kept probabilities are multiplied by it
   int hpb;                   // heads per workgroup (per-sequence kernels): the block is hpb independent groups of waves,
   int lds_per_head;          // each with its own LDS region; heads % hpb == 0
 };

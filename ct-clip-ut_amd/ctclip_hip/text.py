@@ -5,8 +5,11 @@ object -- its parameters, names and state-dict keys are untouched -- and, when i
 runs the encoder through the same gfx950 kernels as CT-ViT: fused QKV GEMM, LDS-staged softmax attention
 with the padding mask (d_head 64), post-LN residual blocks, erf-GELU MLP.
 
-Absolute position embeddings, post-LayerNorm, erf GELU (BertConfig defaults, and CXR-BERT's).  Dropout
-inside the text encoder is not implemented: configs with dropout > 0 raise in train mode.
+Absolute position embeddings, post-LayerNorm, erf GELU (BertConfig defaults, and CXR-BERT's).  In train mode the
+config's dropouts apply where transformers applies them: after the embedding LayerNorm, on the attention probabilities
+(keep flags drawn here, applied inside the attention kernels: ctclip_attn_fwd_dropout / _bwd_dropout) and on the two dense
+outputs before their residual adds.  The random stream is torch's generator on the device, not a replay of the
+reference's: parity with dropout on is statistical, the p = 0 path is what the golden vectors pin.
 """
 from __future__ import annotations
 
@@ -61,39 +64,79 @@ class BertEmbedFn(Function):
         return None, None, r(dword, k3), r(dpos, k4), r(dtype_, k5), r(dlw, k1), r(dlb, k2), None
 
 
+def _dropped(g32, g16, keep, p_drop):
+    """Gradient of the dense branch behind a hidden-state dropout: (f32, bf16) of g * keep / (1 - p); the inputs pass
+    through when there was no dropout."""
+    if keep is None:
+        return g32, g16
+    d = g32 * keep.to(F32) * (1.0 / (1.0 - p_drop))
+    return d, d.to(BF16)
+
+
+def _attn_bwd(ctx_drop, *args):
+    """hip.attn_bwd, or its dropout form with the forward's keep flags spliced in after `mask`."""
+    keep_a, p_att = ctx_drop[0], ctx_drop[4]
+    if keep_a is None:
+        return hip.attn_bwd(*args)
+    return hip.attn_bwd_dropout(*args[:12], keep_a, 1.0 / (1.0 - p_att), *args[12:])
+
+
 class BertLayerFn(Function):
     """One post-LN encoder layer on x [B*L, H] f32.  p = (qw,qb,kw,kb,vw,vb,aow,aob,l1w,l1b,iw,ib,ow,ob,l2w,l2b)."""
 
     @staticmethod
     def forward(ctx, x, mask_add, sh, cfg, *p):
-        B, L, heads, dh, dp, eps = cfg
+        B, L, heads, dh, dp, eps = cfg[:6]
+        p_hid, p_att = (cfg[6], cfg[7]) if len(cfg) > 6 else (0.0, 0.0)      # training-mode dropout (0 = none)
         M, Hd = x.shape
         inner = heads * dp
         I = sh["inter"]
+        dev = x.device
         xb = ops.cast16(x)
         qkv = ops.gemm(xb, sh["wqkv"], M, 3 * inner, Hd, bias=sh["bqkv"])
-        o = torch.empty(M, inner, dtype=BF16, device=x.device)
-        lse = torch.empty(B, heads, L, dtype=F32, device=x.device)
+        o = torch.empty(M, inner, dtype=BF16, device=dev)
+        lse = torch.empty(B, heads, L, dtype=F32, device=dev)
         scale = 1.0 / math.sqrt(dh)
-        hip.attn_fwd(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, lse, None, mask_add, B, L, heads, dp,
-                     3 * inner, 3 * inner, 3 * inner, inner, scale)
-        a = ops.gemm(o, sh["wao"], M, Hd, inner, out_dtype=F32, bias=p[7].detach(), resid=x)
+        # BertSelfAttention drops attention probabilities, BertSelfOutput / BertOutput drop the dense output before the
+        # residual add (transformers modeling_bert.py).  The keep flags are drawn here (torch's generator) and handed to
+        # the kernels / applied element-wise; the p = 0 path below is untouched by any of it.
+        keep_a = keep1 = keep2 = None
+        if p_att > 0:
+            keep_a = (torch.rand(B, heads, L, L, device=dev) >= p_att).to(torch.uint8)
+            hip.attn_fwd_dropout(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, lse, None, mask_add, keep_a, 1.0 / (1.0 - p_att),
+                                 B, L, heads, dp, 3 * inner, 3 * inner, 3 * inner, inner, scale)
+        else:
+            hip.attn_fwd(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, lse, None, mask_add, B, L, heads, dp,
+                         3 * inner, 3 * inner, 3 * inner, inner, scale)
+        if p_hid > 0:
+            keep1 = torch.rand(M, Hd, device=dev) >= p_hid
+            ad = ops.gemm(o, sh["wao"], M, Hd, inner, out_dtype=F32, bias=p[7].detach())
+            a = torch.addcmul(x, ad, keep1.to(F32), value=1.0 / (1.0 - p_hid))
+        else:
+            a = ops.gemm(o, sh["wao"], M, Hd, inner, out_dtype=F32, bias=p[7].detach(), resid=x)
         x1_16, x1, mean1, rstd1 = ops.layernorm(a, p[8].detach(), p[9].detach(), eps, want16=True, want32=True)
         hpre = ops.gemm(x1_16, sh["wi"], M, I, Hd, bias=p[11].detach())
         m = torch.empty_like(hpre)
         hip.gelu_fwd(hpre, m, hpre.numel())
-        o2 = ops.gemm(m, sh["wo"], M, Hd, I, out_dtype=F32, bias=p[13].detach(), resid=x1)
+        if p_hid > 0:
+            keep2 = torch.rand(M, Hd, device=dev) >= p_hid
+            od = ops.gemm(m, sh["wo"], M, Hd, I, out_dtype=F32, bias=p[13].detach())
+            o2 = torch.addcmul(x1, od, keep2.to(F32), value=1.0 / (1.0 - p_hid))
+        else:
+            o2 = ops.gemm(m, sh["wo"], M, Hd, I, out_dtype=F32, bias=p[13].detach(), resid=x1)
         _, x2, mean2, rstd2 = ops.layernorm(o2, p[14].detach(), p[15].detach(), eps, want16=False, want32=True)
         ctx.save_for_backward(xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, p[8], p[14],
                               mask_add if mask_add is not None else x.new_empty(0))
         ctx.sh, ctx.cfg, ctx.params = sh, cfg, p
+        ctx.drop = (keep_a, keep1, keep2, p_hid, p_att)
         return x2
 
     @staticmethod
     def backward(ctx, dy):
         xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, l1w, l2w, mask_add = ctx.saved_tensors
         sh = ctx.sh
-        B, L, heads, dh, dp, eps = ctx.cfg
+        B, L, heads, dh, dp, eps = ctx.cfg[:6]
+        keep_a, keep1, keep2, p_hid, p_att = ctx.drop
         M, Hd = a.shape
         inner, I = heads * dp, sh["inter"]
         dev = dy.device
@@ -108,7 +151,8 @@ class BertLayerFn(Function):
         do2 = torch.empty(M, Hd, dtype=F32, device=dev)
         do2b = torch.empty(M, Hd, dtype=BF16, device=dev)
         hip.layernorm_bwd(ops._c(dy), o2, l2w, mean2, rstd2, None, do2, do2b, g[14], g[15], M, Hd)
-        ops.colsum(do2, out=g[13])
+        dod, do2b = _dropped(do2, do2b, keep2, p_hid)          # into the dense branch; the residual keeps do2 itself
+        ops.colsum(dod, out=g[13])
         dm = ops.dgrad(do2b, sh["wo"], M, Hd, I, out_dtype=BF16, wT16=sh.get("woT"))
         ops.wgrad(do2b, m, Hd, I, M, out=g[12])
         dh_ = torch.empty_like(hpre)
@@ -120,15 +164,16 @@ class BertLayerFn(Function):
         da = torch.empty(M, Hd, dtype=F32, device=dev)
         dab = torch.empty(M, Hd, dtype=BF16, device=dev)
         hip.layernorm_bwd(dx1, a, l1w, mean1, rstd1, None, da, dab, g[8], g[9], M, Hd)
-        ops.colsum(da, out=g[7])
+        dad, dab = _dropped(da, dab, keep1, p_hid)
+        ops.colsum(dad, out=g[7])
         do = ops.dgrad(dab, sh["wao"], M, Hd, inner, out_dtype=BF16, wT16=sh.get("waoT"))
         ops.wgrad(dab, o, Hd, inner, M, out=g[6])
         dqkv = torch.empty(M, 3 * inner, dtype=BF16, device=dev)
         delta = torch.empty(B, heads, L, dtype=F32, device=dev)
-        hip.attn_bwd(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, do, lse, delta, dqkv, dqkv[:, inner:],
-                     dqkv[:, 2 * inner:], None, mask_add, None, None, None, 0, 0, 0, B, L, heads, dp,
-                     3 * inner, 3 * inner, 3 * inner, inner, inner, 3 * inner, 3 * inner, 3 * inner,
-                     1.0 / math.sqrt(dh))
+        _attn_bwd(ctx.drop, qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, do, lse, delta, dqkv, dqkv[:, inner:],
+                  dqkv[:, 2 * inner:], None, mask_add, None, None, None, 0, 0, 0, B, L, heads, dp,
+                  3 * inner, 3 * inner, 3 * inner, inner, inner, 3 * inner, 3 * inner, 3 * inner,
+                  1.0 / math.sqrt(dh))
         for j in range(3):                                  # query / key / value: weight and bias
             part = dqkv[:, j * inner:(j + 1) * inner]
             ops.colsum(part, out=g[2 * j + 1])
@@ -141,7 +186,8 @@ class BertLayerFn(Function):
         """Head dims below 32 (toy configs): kernels run on zero-padded heads, gradients are un-padded afterwards."""
         xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, l1w, l2w, mask_add = ctx.saved_tensors
         sh = ctx.sh
-        B, L, heads, dh, dp, eps = ctx.cfg
+        B, L, heads, dh, dp, eps = ctx.cfg[:6]
+        keep_a, keep1, keep2, p_hid, p_att = ctx.drop
         M, Hd = a.shape
         inner, I = heads * dp, sh["inter"]
         dev = dy.device
@@ -153,7 +199,8 @@ class BertLayerFn(Function):
         do2b = torch.empty(M, Hd, dtype=BF16, device=dev)
         dl2w, dl2b = z(Hd), z(Hd)
         hip.layernorm_bwd(ops._c(dy), o2, l2w, mean2, rstd2, None, do2, do2b, dl2w, dl2b, M, Hd)
-        dbo = ops.colsum(do2)
+        dod, do2b = _dropped(do2, do2b, keep2, p_hid)
+        dbo = ops.colsum(dod)
         dm = ops.dgrad(do2b, sh["wo"], M, Hd, I, out_dtype=BF16, wT16=sh.get("woT"))
         dwo = ops.wgrad(do2b, m, Hd, I, M)
         dh_ = torch.empty_like(hpre)
@@ -166,15 +213,16 @@ class BertLayerFn(Function):
         dab = torch.empty(M, Hd, dtype=BF16, device=dev)
         dl1w, dl1b = z(Hd), z(Hd)
         hip.layernorm_bwd(dx1, a, l1w, mean1, rstd1, None, da, dab, dl1w, dl1b, M, Hd)
-        dbao = ops.colsum(da)
+        dad, dab = _dropped(da, dab, keep1, p_hid)
+        dbao = ops.colsum(dad)
         do = ops.dgrad(dab, sh["wao"], M, Hd, inner, out_dtype=BF16, wT16=sh.get("waoT"))
         dwao = ops.wgrad(dab, o, Hd, inner, M)
         dqkv = torch.empty(M, 3 * inner, dtype=BF16, device=dev)
         delta = torch.empty(B, heads, L, dtype=F32, device=dev)
-        hip.attn_bwd(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, do, lse, delta, dqkv, dqkv[:, inner:],
-                     dqkv[:, 2 * inner:], None, mask_add, None, None, None, 0, 0, 0, B, L, heads, dp,
-                     3 * inner, 3 * inner, 3 * inner, inner, inner, 3 * inner, 3 * inner, 3 * inner,
-                     1.0 / math.sqrt(dh))
+        _attn_bwd(ctx.drop, qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, do, lse, delta, dqkv, dqkv[:, inner:],
+                  dqkv[:, 2 * inner:], None, mask_add, None, None, None, 0, 0, 0, B, L, heads, dp,
+                  3 * inner, 3 * inner, 3 * inner, inner, inner, 3 * inner, 3 * inner, 3 * inner,
+                  1.0 / math.sqrt(dh))
         dbqkv = ops.colsum(dqkv)
         dx = ops.dgrad(dqkv, sh["wqkv"], M, 3 * inner, Hd, resid=da, wT16=sh.get("wqkvT"))
         dwqkv = ops.wgrad(dqkv, xb, 3 * inner, Hd, M)
@@ -224,10 +272,10 @@ def bert_last_hidden_state(model, input_ids, token_type_ids=None, attention_mask
         raise NotImplementedError("only absolute position embeddings are implemented")
     if cfg.hidden_act not in ("gelu",):
         raise NotImplementedError(f"hidden_act={cfg.hidden_act!r}: only erf-GELU is implemented")
-    if model.training and (cfg.hidden_dropout_prob > 0 or cfg.attention_probs_dropout_prob > 0):
-        raise NotImplementedError("dropout inside the text encoder is not implemented on the HIP path: "
-                                  "construct the BertModel with hidden_dropout_prob=attention_probs_dropout_prob=0 "
-                                  "or call .eval() on it")
+    p_hid = float(cfg.hidden_dropout_prob) if model.training else 0.0
+    p_att = float(cfg.attention_probs_dropout_prob) if model.training else 0.0
+    if not (0.0 <= p_hid < 1.0 and 0.0 <= p_att < 1.0):
+        raise ValueError("dropout probabilities must be in [0, 1)")
     B, L = input_ids.shape
     Hd, heads = cfg.hidden_size, cfg.num_attention_heads
     if Hd % 8 or cfg.intermediate_size % 8:
@@ -238,10 +286,12 @@ def bert_last_hidden_state(model, input_ids, token_type_ids=None, attention_mask
     x = BertEmbedFn.apply(input_ids, token_type_ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
                           emb.token_type_embeddings.weight, emb.LayerNorm.weight, emb.LayerNorm.bias,
                           float(cfg.layer_norm_eps))
+    if p_hid > 0:
+        x = torch.nn.functional.dropout(x, p_hid, True)          # BertEmbeddings.dropout, after its LayerNorm
     mask_add = None
     if attention_mask is not None:
         mask_add = ((1.0 - attention_mask.to(F32)) * torch.finfo(F32).min).contiguous()
-    lcfg = (B, L, heads, dh, dp, float(cfg.layer_norm_eps))
+    lcfg = (B, L, heads, dh, dp, float(cfg.layer_norm_eps), p_hid, p_att)
     for layer in model.encoder.layer:
         x = BertLayerFn.apply(x, mask_add, _layer_shadows(layer, heads, dh, dp), lcfg, *_layer_params(layer))
     return x.reshape(B, L, Hd)

@@ -87,6 +87,19 @@ int ctclip_attn_bwd(const void* q, const void* k, const void* v, const void* o, 
                     float* dbias_dense, const uint16_t* relidx, float* dbias_table, int table_size, int grid_h, int grid_w,
                     int nseq, int n, int heads, int dhead, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq,
                     long lddk, long lddv, float scale, void* stream);
+/* The same pair with attention-probability dropout (transformers BertSelfAttention: `attention_probs = self.dropout(
+ * attention_probs)`, modeling_bert.py): `keep` [nseq, heads, n, n] holds one byte per probability (non-zero = kept), drawn by
+ * the caller; kept probabilities are multiplied by keep_scale = 1/(1-p) on their way into P.V, the softmax normaliser and
+ * lse are those of the undropped row.  The backward applies the same flags, so the two passes agree by construction. */
+int ctclip_attn_fwd_dropout(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
+                            const float* mask, const uint8_t* keep, float keep_scale, int nseq, int n, int heads, int dhead,
+                            long ldq, long ldk, long ldv, long ldo, float scale, void* stream);
+int ctclip_attn_bwd_dropout(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
+                            float* delta, void* dq, void* dk, void* dv, const float* bias, const float* mask,
+                            const uint8_t* keep, float keep_scale, float* dbias_dense, const uint16_t* relidx,
+                            float* dbias_table, int table_size, int grid_h, int grid_w, int nseq, int n, int heads, int dhead,
+                            long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale,
+                            void* stream);
 /* probabilities [nseq,heads,n,n] f32, for callers that want Attention.forward's second output */
 int ctclip_attn_probs(const void* q, const void* k, const float* lse, const float* bias, const float* mask,
                       float* probs, int nseq, int n, int heads, int dhead, long ldq, long ldk, float scale,

@@ -260,6 +260,63 @@ def test_vq_topk_whole_code_tiles(hip, C_, T, K):
     assert int(idx[T - 1]) == 0 and bool(((idx >= 0) & (idx < C_)).all())
 
 
+@pytest.mark.parametrize("nseq,n,H,D,use_bias,use_mask", [
+    (3, 128, 4, 64, False, True),      # BERT shape with a padding mask
+    (2, 40, 2, 32, True, False),       # ragged rows, dense bias and its gradient
+    (2, 6, 3, 64, False, True),        # n % 4 != 0: byte-wise flag reads
+    (2, 64, 2, 32, False, False),      # would take the sequence-persistent kernels without dropout
+    (4, 24, 2, 32, False, False),      # would take the one-wave backward without dropout
+])
+def test_attention_probability_dropout(hip, nseq, n, H, D, use_bias, use_mask):
+    """ctclip_attn_fwd_dropout / _bwd_dropout (transformers BertSelfAttention): softmax over all keys, then the kept
+    probabilities scaled by 1/(1-p) go into P.V; the backward uses the same flags.  p = 0.25, flags from the caller."""
+    pdrop = 0.25
+    scale = 1.0 / math.sqrt(D)
+    ld = H * D
+    q, k, v, do = (bf(rnd(nseq * n, ld, seed=s)) for s in (40, 41, 42, 43))
+    bias = rnd(H, n, n, seed=44) if use_bias else None
+    mask = None
+    if use_mask:
+        lens = torch.randint(max(1, n // 2), n + 1, (nseq,), generator=torch.Generator().manual_seed(6))
+        lens[0] = n
+        mask = ((torch.arange(n)[None] >= lens[:, None]).float() * torch.finfo(torch.float32).min).to(DEV)
+    keep = (torch.rand(nseq, H, n, n, generator=torch.Generator().manual_seed(9)) >= pdrop).to(torch.uint8).to(DEV)
+    sp = lambda t: t.float().reshape(nseq, n, H, D).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    qr, kr, vr = sp(q), sp(k), sp(v)
+    br = bias.clone().requires_grad_(True) if use_bias else None
+    s = torch.einsum("shid,shjd->shij", qr, kr) * scale
+    if br is not None:
+        s = s + br[None]
+    if mask is not None:
+        s = s + mask[:, None, None, :]
+    pref = s.softmax(-1) * keep.float() / (1.0 - pdrop)
+    oref = torch.einsum("shij,shjd->shid", pref, vr)
+    o = torch.empty(nseq * n, ld, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(nseq, H, n, device=DEV)
+    hip.attn_fwd_dropout(q, k, v, o, lse, bias, mask, keep, 1.0 / (1.0 - pdrop), nseq, n, H, D, ld, ld, ld, ld, scale)
+    un = lambda t: t.float().reshape(nseq, n, H, D).permute(0, 2, 1, 3)
+    check("dropout attn out", un(o), oref, 2e-2)
+    check("lse is the undropped row's", lse, torch.logsumexp(s.detach(), -1), 1e-3)
+    oref.backward(un(do))
+    dq, dk, dv = (torch.empty(nseq * n, ld, device=DEV, dtype=torch.bfloat16) for _ in range(3))
+    delta = torch.empty(nseq, H, n, device=DEV)
+    dbias = torch.zeros(H, n, n, device=DEV) if use_bias else None
+    hip.attn_bwd_dropout(q, k, v, o, do, lse, delta, dq, dk, dv, bias, mask, keep, 1.0 / (1.0 - pdrop), dbias, None, None, 0,
+                         0, 0, nseq, n, H, D, ld, ld, ld, ld, ld, ld, ld, ld, scale)
+    check("dropout attn dq", un(dq), qr.grad, 3e-2)
+    check("dropout attn dk", un(dk), kr.grad, 3e-2)
+    check("dropout attn dv", un(dv), vr.grad, 3e-2)
+    if use_bias:
+        check("dropout attn dbias", dbias, br.grad, 3e-2)
+    # all flags set and scale 1 is the plain kernel pair
+    ones = torch.ones_like(keep)
+    o2 = torch.empty_like(o)
+    hip.attn_fwd_dropout(q, k, v, o2, lse, bias, mask, ones, 1.0, nseq, n, H, D, ld, ld, ld, ld, scale)
+    o3 = torch.empty_like(o)
+    hip.attn_fwd(q, k, v, o3, lse, bias, mask, nseq, n, H, D, ld, ld, ld, ld, scale)
+    check("keep-all == no dropout", o2, o3.float(), 1e-2)
+
+
 # ---------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("B,A,C,dim", [(2, 3, 5, 512), (1, 24, 7, 64), (3, 4, 4, 56)])
 def test_layernorm_with_token_reordering(hip, B, A, C, dim):

@@ -172,6 +172,74 @@ def test_bert_golden():
     check("bert hidden (valid tokens)", hid.cpu()[mask], g["last_hidden_state"][mask], 3e-2)
 
 
+def test_bert_layer_with_dropout_vs_torch_same_flags():
+    """One encoder layer in train mode with the config's dropouts (transformers BertSelfAttention / BertSelfOutput /
+    BertOutput) against plain torch f32 math that draws the same keep flags: re-seeding torch's device generator before
+    each run makes the torch.rand calls of ctclip_hip.text.BertLayerFn reproducible, in its order (attention flags, then
+    the two hidden-state flags)."""
+    from transformers import BertConfig, BertModel
+    from ctclip_hip.text import BertLayerFn, _layer_params, _layer_shadows
+    torch.manual_seed(3)
+    B, L, Hd, heads, I = 3, 32, 128, 2, 256
+    p_hid, p_att = 0.2, 0.3
+    cfg = BertConfig(hidden_size=Hd, num_hidden_layers=1, num_attention_heads=heads, intermediate_size=I, vocab_size=50,
+                     max_position_embeddings=L, hidden_dropout_prob=p_hid, attention_probs_dropout_prob=p_att)
+    layer = BertModel(cfg).to(DEV).train().encoder.layer[0]
+    dh = Hd // heads
+    x0 = torch.randn(B * L, Hd, device=DEV)
+    lens = torch.tensor([L, L // 2, L - 5])
+    mask_add = ((torch.arange(L)[None] >= lens[:, None]).float() * torch.finfo(torch.float32).min).to(DEV)
+    dy = torch.randn(B * L, Hd, device=DEV)
+    P = _layer_params(layer)
+
+    # reference with the same flags
+    torch.manual_seed(77)
+    keep_a = (torch.rand(B, heads, L, L, device=DEV) >= p_att).float() / (1 - p_att)
+    keep1 = (torch.rand(B * L, Hd, device=DEV) >= p_hid).float() / (1 - p_hid)
+    keep2 = (torch.rand(B * L, Hd, device=DEV) >= p_hid).float() / (1 - p_hid)
+    xr = x0.clone().requires_grad_(True)
+    lin = torch.nn.functional.linear
+    split = lambda t: t.reshape(B, L, heads, dh).permute(0, 2, 1, 3)
+    q, k, v = split(lin(xr, P[0], P[1])), split(lin(xr, P[2], P[3])), split(lin(xr, P[4], P[5]))
+    s_ = q @ k.transpose(-1, -2) / math.sqrt(dh) + mask_add[:, None, None, :]
+    ctxv = ((s_.softmax(-1) * keep_a) @ v).permute(0, 2, 1, 3).reshape(B * L, Hd)
+    a = torch.nn.functional.layer_norm(lin(ctxv, P[6], P[7]) * keep1 + xr, (Hd,), P[8], P[9], cfg.layer_norm_eps)
+    h = torch.nn.functional.gelu(lin(a, P[10], P[11]))
+    ref = torch.nn.functional.layer_norm(lin(h, P[12], P[13]) * keep2 + a, (Hd,), P[14], P[15], cfg.layer_norm_eps)
+    ref.backward(dy)
+    ref_grads = {i: P[i].grad.clone() for i in (0, 6, 7, 10, 12, 13, 14)}
+    for t in P:
+        t.grad = None
+
+    torch.manual_seed(77)
+    xh = x0.clone().requires_grad_(True)
+    lcfg = (B, L, heads, dh, ops_head_pad(dh), float(cfg.layer_norm_eps), p_hid, p_att)
+    out = BertLayerFn.apply(xh, mask_add, _layer_shadows(layer, heads, dh, ops_head_pad(dh)), lcfg, *P)
+    out.backward(dy)
+    torch.cuda.synchronize()
+    valid = (torch.arange(L)[None] < lens[:, None]).reshape(-1).to(DEV)
+    check("layer output", out[valid], ref[valid], 3e-2)
+    check("input gradient", xh.grad, xr.grad, 5e-2)
+    for i, g in ref_grads.items():
+        check(f"parameter {i} gradient", P[i].grad, g, 6e-2)
+    # eval mode of the whole model: dropouts off, two calls agree exactly
+    from ctclip_hip.text import bert_last_hidden_state
+    m = BertModel(cfg).to(DEV)
+    ids = torch.randint(0, 50, (B, L), device=DEV)
+    m.eval()
+    e1 = bert_last_hidden_state(m, ids)
+    e2 = bert_last_hidden_state(m, ids)
+    assert torch.equal(e1, e2)
+    m.train()
+    t1 = bert_last_hidden_state(m, ids)
+    assert not torch.equal(t1, e1) and bool(torch.isfinite(t1).all())
+
+
+def ops_head_pad(dh):
+    from ctclip_hip import ops
+    return ops.head_pad(dh)
+
+
 def build_clip(g):
     from transformers import BertConfig, BertModel
     from models.ctclip import CTCLIP
