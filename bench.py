@@ -54,6 +54,25 @@ def synthetic_batch(B, depth, size, L, vocab, device, rank, dtype=torch.bfloat16
     return vol, txt
 
 
+def gemm_traffic(args):
+    """HBM-side bytes per GEMM launch.  bench.py cannot collect PMC counters itself; the figure comes from the committed
+    rocprofv3 passes of this same command (profiles/r01_i_hbm_traffic_b64.csv: separate FETCH_SIZE / WRITE_SIZE runs, read
+    side doubled as MI355X_MICROARCH.md prescribes for gfx950) and is reported only for the configuration they were taken on."""
+    path = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic_b64.csv")
+    if args.small or args.batch != 64 or not os.path.exists(path):
+        return {"traffic": None}
+    launches = total = 0.0
+    for line in open(path):
+        f = line.rsplit(",", 4)
+        if len(f) == 5 and f[0].split("::")[-1].startswith(("gemm3_kernel", "gemm4_kernel", "gemm2_kernel", "gemm_bf16_kernel")):
+            launches += float(f[1])
+            total += float(f[1]) * float(f[4]) * 1e6
+    if launches == 0:
+        return {"traffic": None}
+    return {"traffic": total / launches, "traffic_unit": "bytes per launch (mean over the family)",
+            "traffic_source": "profiles/r01_i_hbm_traffic_b64.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+
+
 def cpu_baseline(model, depth, size, L, vocab):
     """The oracle (oracle/ctclip_oracle.py: op-for-op f32 restatement of the reference, pinned by golden vectors) timed
     on the host cores.  A full-depth production step takes many minutes on a CPU, so the sample is bounded: every DISTINCT
@@ -242,7 +261,7 @@ def main():
             "roofline": {"kernel": "ctclip_gemm_bf16 family (gemm3_kernel 256x256x32 four-stage LDS-DMA ring for the k-major products, "
                                    "gemm4_kernel, the same tile with transposed operands, for weight gradients, gemm2/gemm_bf16 kernels for small grids)", "bound": "mfma", "achieved": gemm_tflops,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_BF16_TFLOPS,
-                         "traffic": None, "launches_per_step": timing["launches"] / args.steps,
+                         **gemm_traffic(args), "launches_per_step": timing["launches"] / args.steps,
                          "gemm_ms_per_step": timing["total_ms"] / args.steps,
                          "achieved_without_stream_overlap": alone["work"] / (alone["total_ms"] * 1e-3) / 1e12,
                          "note": "achieved: HIP-event durations inside the timed region, where weight-gradient GEMMs run "
