@@ -143,6 +143,16 @@ def on_side_stream(fn, *pinned):
     return r
 
 
+def side_stream_for_collectives():
+    """The weight-gradient stream, for GradSync: a collective issued from it (after it has been made to wait for the main
+    stream) orders after the gradient kernels of BOTH streams.  None when everything runs on one stream."""
+    if not _side["on"] or not torch.cuda.is_available():
+        return None
+    if _side["stream"] is None:
+        _side["stream"] = torch.cuda.Stream()
+    return _side["stream"]
+
+
 def _wgrad_now(dy16, x16, n_feat, k_feat, tokens, out):
     hip.gemm_bf16(dy16, x16, out, None, None, n_feat, k_feat, tokens, dy16.stride(0), x16.stride(0), out.stride(0), 0,
                   0, 0, 1, _splits_for(n_feat, k_feat, tokens), 1, 1.0, 0)
@@ -208,12 +218,14 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def grad_slot(p):
+def grad_slot(p, note=True):
     """-> (buffer, direct).  Every gradient kernel ACCUMULATES (f32 atomics), so when the parameter already owns a
     contiguous f32 .grad (the flat arena of ctclip_hip.optim.HipAdam pre-binds one) the kernels add straight into
     it and the Function returns None for that input: no zero-fill, no extra `grad += new` pass per tensor."""
     g = p.grad
     if g is not None and g.dtype == F32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device:
+        if note and grad_ready_hook is not None:
+            _issued.append(p)
         return g, True
     return torch.zeros(p.shape, dtype=F32, device=p.device), False
 
@@ -223,8 +235,33 @@ def _ret(buf, direct):
 
 
 # Optional callback(param) fired by a backward as soon as a parameter's gradient has been fully ISSUED into its arena slot.
-# GradSync installs it to start that slice's RCCL all-reduce early (overlap with the rest of backward).
+# GradSync installs it to start that bucket's RCCL all-reduce early (overlap with the rest of backward).  Parameters whose
+# gradient autograd delivers (a Function that returns it) are reported by a post-accumulate hook instead; the ones below
+# accumulate in place and return None, so the Function itself has to say when it is done: grad_slot() notes the parameter,
+# announce_grads() at the end of the backward reports every noted one.
 grad_ready_hook = None
+_issued = []
+
+
+def announce_grads():
+    if _issued:
+        ps = list(_issued)
+        _issued.clear()
+        hook = grad_ready_hook
+        if hook is not None:
+            for p in ps:
+                hook(p)
+
+
+def announces(backward):
+    """Decorator for a Function.backward that accumulates parameter gradients in place: report them once it has issued
+    all of its kernels."""
+    def wrapped(ctx, *grads):
+        out = backward(ctx, *grads)
+        announce_grads()
+        return out
+    wrapped.__name__ = backward.__name__
+    return wrapped
 
 
 def _grad_ready(p, direct):
@@ -277,6 +314,7 @@ class LayerNormFn(Function):
         return y
 
     @staticmethod
+    @announces
     def backward(ctx, dy):
         x2, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.params
@@ -316,6 +354,7 @@ class PegFn(Function):
         return y, y16
 
     @staticmethod
+    @announces
     def backward(ctx, dy, _dy16):
         if dy is None:
             return None, None, None, None, None
@@ -327,9 +366,11 @@ class PegFn(Function):
         hip.peg_bwd_data(dyc, w27, dx, dx16, b, t, h, w, d, residual)
         _tag16(dx, dx16)
         p_w, p_b = ctx.params
-        gw, dw_direct = grad_slot(p_w)
-        gb, db_direct = grad_slot(p_b)
+        gw, dw_direct = grad_slot(p_w, note=False)
+        gb, db_direct = grad_slot(p_b, note=False)
         if dw_direct and db_direct:
+            if grad_ready_hook is not None:
+                _issued.extend((p_w, p_b))
             # HBM-bound and off the critical path: on the side stream it shares the chip with the matrix-bound GEMMs of the
             # layer whose backward comes next; the tap-major result is folded into the [d,1,3,3,3] gradient there too
             def peg_wgrad():
@@ -395,6 +436,7 @@ class AttentionFn(Function):
         return y.reshape(nseq, n, dim), probs
 
     @staticmethod
+    @announces
     def backward(ctx, dy, _dprobs):
         x2, gamma, mean, rstd, n1, xb, q, kv, qh, kh, qinv, kinv, o, lse, bias_dense = ctx.saved_tensors
         sh, aux = ctx.sh, ctx.aux
@@ -496,6 +538,7 @@ class FeedForwardFn(Function):
         return y.reshape(shape)
 
     @staticmethod
+    @announces
     def backward(ctx, dy):
         x2, ln_w, mean, rstd, n2, h, g = ctx.saved_tensors
         if getattr(ctx, "h_consumed", False):
@@ -606,6 +649,7 @@ class PatchEmbedFn(Function):
         return y.reshape(B, t, h, wt, dim)
 
     @staticmethod
+    @announces
     def backward(ctx, dy):
         vol, A, mean1, rstd1, z, mean2, rstd2, ln2w = ctx.saved_tensors
         sh = ctx.sh
@@ -701,15 +745,18 @@ class VQFn(Function):
         return dx.reshape(dq.shape), None, None, None
 
 
-def vq_ema_update(x2, inv, idx, embed, cluster_size, decay, all_reduce=None):
-    """EMA codebook update of the library's cosine-sim codebook (in place on the buffers)."""
-    ncodes, d = embed.shape[-2], embed.shape[-1]
-    bins = torch.zeros(ncodes, dtype=F32, device=x2.device)
-    esum = torch.zeros(ncodes, d, dtype=F32, device=x2.device)
+def vq_ema_accum(x2, inv, idx, ncodes, d):
+    """Per-code statistics of the library's cosine-sim codebook update: -> (bins [ncodes], esum [ncodes, d], flat), the
+    first two being views of the one flat buffer (so a data-parallel run reduces both with one collective)."""
+    flat = torch.zeros(ncodes * (d + 1), dtype=F32, device=x2.device)
+    bins, esum = flat[:ncodes], flat[ncodes:].view(ncodes, d)
     hip.vq_ema_accum(x2, inv, idx.reshape(-1), bins, esum, x2.shape[0], d)
-    if all_reduce is not None:
-        all_reduce(bins)
-        all_reduce(esum)
+    return bins, esum, flat
+
+
+def vq_ema_apply(embed, cluster_size, bins, esum, decay):
+    """EMA codebook update from (reduced) statistics, in place on the buffers."""
+    ncodes, d = embed.shape[-2], embed.shape[-1]
     hip.vq_ema_update(embed.reshape(ncodes, d), cluster_size.reshape(ncodes), bins, esum, ncodes, d, float(decay))
 
 

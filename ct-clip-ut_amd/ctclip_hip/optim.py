@@ -6,11 +6,14 @@ views of it), and so do their gradients and the two Adam moments.  The optimiser
 launches over flat memory (sum of squares, then clip+Adam with the clip coefficient computed on device -- no
 host sync), and data-parallel gradient averaging is a handful of large RCCL all-reduces over slices of the flat
 gradient buffer instead of one NCCL call per tensor bucket copy.
+
+Checkpoint format: `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format (per-parameter `step`,
+`exp_avg`, `exp_avg_sq`, index-packed `param_groups` with Adam's group keys), so the "optim" entry of a reference
+checkpoint (CTClipTrainer.py:136-154) loads here and one written here loads into the reference's Adam/AdamW.
 """
 from __future__ import annotations
 
-import math
-from typing import Iterable, Optional
+from typing import Optional
 
 import torch
 import torch.distributed as dist
@@ -20,31 +23,45 @@ from .lib import hip
 
 F32 = torch.float32
 
+# group keys torch.optim.Adam / AdamW carry (torch 2.x); kept in every group so an exported state dict loads into them
+_TORCH_ADAM_KEYS = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+
+
+def mark_unused(p: torch.Tensor) -> None:
+    """Tag a parameter that never receives a gradient on the CT-CLIP path.  HipAdam keeps it in
+    `param_groups` (so parameter indices equal the reference's `get_optimizer(model.parameters())`) but gives it no
+    arena slot -- torch's Adam likewise never creates state for a parameter whose grad stays None."""
+    p._ctclip_unused = True
+
 
 class HipAdam(torch.optim.Optimizer):
-    """Adam (decoupled=False) / AdamW (decoupled=True) over flat arenas.  Same hyper-parameter names and defaults
-    handling as torch.optim.Adam/AdamW; `step(max_grad_norm=...)` additionally fuses clip_grad_norm_."""
+    """Adam (decoupled_weight_decay=False) / AdamW (True) over flat arenas.  Same hyper-parameter names and group keys
+    as torch.optim.Adam/AdamW; `step(max_grad_norm=...)` additionally fuses clip_grad_norm_."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
-        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled)
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
+                 amsgrad=False, maximize=False, **torch_adam_flags):
+        if amsgrad or maximize:
+            raise NotImplementedError("amsgrad / maximize are not implemented by the fused HIP step")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **_TORCH_ADAM_KEYS,
+                        decoupled_weight_decay=bool(decoupled))
         super().__init__(params, defaults)
         self._built = False
         self._step = 0
-        self._arenas = []       # per group: dict(p=, g=, m=, v=, params=[...])
+        self._arenas = []       # per group: dict(p=, g=, m=, v=, params=[...], offs=[...]) or None
         self._gnorm_sq = None
         self.last_grad_norm_sq = None
 
     # -- arena construction (lazy: parameters may be moved to the GPU after the optimiser was created) ------
     def _build(self):
+        self._arenas = []
         for group in self.param_groups:
-            ps = [p for p in group["params"] if p.requires_grad]
+            ps = [p for p in group["params"] if p.requires_grad and not getattr(p, "_ctclip_unused", False)]
             if not ps:
                 self._arenas.append(None)
                 continue
             dev = ps[0].device
-            if any((not p.is_cuda) or p.dtype != F32 or p.device != dev for p in ps):
-                raise RuntimeError("HipAdam needs float32 parameters on one cuda device: the optimiser step runs as "
-                                   "HIP kernels and has no CPU fallback")
+            if any(p.dtype != F32 or p.device != dev for p in ps):
+                raise RuntimeError("HipAdam needs float32 parameters on one device")
             offs, total = [], 0
             for p in ps:
                 offs.append(total)
@@ -59,8 +76,10 @@ class HipAdam(torch.optim.Optimizer):
                     p.grad = flat_g[o:o + p.numel()].view(p.shape)
             self._arenas.append(dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p),
                                      params=ps, offs=offs))
-        dev = next(a for a in self._arenas if a is not None)["p"].device
-        self._gnorm_sq = torch.zeros((), dtype=F32, device=dev)
+        live = [a for a in self._arenas if a is not None]
+        if not live:
+            raise RuntimeError("HipAdam: no trainable parameters")
+        self._gnorm_sq = torch.zeros((), dtype=F32, device=live[0]["p"].device)
         self._built = True
         ops.bump_weight_epoch()
 
@@ -69,16 +88,32 @@ class HipAdam(torch.optim.Optimizer):
             self._build()
         return [a["g"] for a in self._arenas if a is not None]
 
+    def _bind_grads(self, adopt: bool):
+        """Make every parameter's .grad the arena view again.  adopt: a gradient somebody assigned as a new tensor
+        (`p.grad = t`, the torch.optim contract) is copied into its slot first; a grad of None counts as zero."""
+        for a in self._arenas:
+            if a is None:
+                continue
+            base = a["g"].data_ptr()
+            for p, o in zip(a["params"], a["offs"]):
+                g = p.grad
+                if g is not None and g.data_ptr() == base + 4 * o and g.dtype == F32:
+                    continue
+                slot = a["g"][o:o + p.numel()].view(p.shape)
+                if adopt:
+                    if g is None:
+                        slot.zero_()
+                    else:
+                        slot.copy_(g)
+                p.grad = slot
+
     def zero_grad(self, set_to_none: bool = False):
         if not self._built:
             self._build()
         for a in self._arenas:
-            if a is None:
-                continue
-            a["g"].zero_()
-            for p, o in zip(a["params"], a["offs"]):
-                if p.grad is None or p.grad.data_ptr() != a["g"].data_ptr() + 4 * o:
-                    p.grad = a["g"][o:o + p.numel()].view(p.shape)
+            if a is not None:
+                a["g"].zero_()
+        self._bind_grads(adopt=False)
 
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm: Optional[float] = None):
@@ -86,6 +121,10 @@ class HipAdam(torch.optim.Optimizer):
             raise NotImplementedError("closures are not supported")
         if not self._built:
             self._build()
+        self._bind_grads(adopt=True)
+        if not self._arenas or not next(a for a in self._arenas if a is not None)["p"].is_cuda:
+            raise RuntimeError("HipAdam.step: parameters are not on a HIP device; the optimiser step runs as HIP kernels "
+                               "and has no CPU fallback")
         self._step += 1
         gn = None
         if max_grad_norm:
@@ -100,7 +139,7 @@ class HipAdam(torch.optim.Optimizer):
                 continue
             b1, b2 = group["betas"]
             hip.adam_step(a["p"], a["g"], a["m"], a["v"], None, a["p"].numel(), float(group["lr"]), float(b1), float(b2),
-                          float(group["eps"]), float(group["weight_decay"]), int(bool(group["decoupled"])),
+                          float(group["eps"]), float(group["weight_decay"]), int(bool(group["decoupled_weight_decay"])),
                           1.0 - b1 ** self._step, 1.0 - b2 ** self._step, gn, float(max_grad_norm or 0.0))
         ops.bump_weight_epoch()
 
@@ -108,91 +147,213 @@ class HipAdam(torch.optim.Optimizer):
         """Global gradient norm seen by the last clipped step (host sync; for logging/tests)."""
         return float(self.last_grad_norm_sq.sqrt()) if self.last_grad_norm_sq is not None else float("nan")
 
+    # -- torch.optim.Adam-format checkpoints -------------------------------------------------------------------
+    def _index_of(self):
+        idx, out = 0, {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                out[id(p)] = idx
+                idx += 1
+        return out
+
     def state_dict(self):
-        sd = super().state_dict()
-        sd["hip"] = {"step": self._step,
-                     "m": [None if a is None else a["m"].clone() for a in self._arenas],
-                     "v": [None if a is None else a["v"].clone() for a in self._arenas]}
-        return sd
+        if not self._built:
+            self._build()
+        index = self._index_of()
+        groups, start = [], 0
+        for group in self.param_groups:
+            packed = {k: v for k, v in group.items() if k != "params"}
+            packed["params"] = list(range(start, start + len(group["params"])))
+            start += len(group["params"])
+            groups.append(packed)
+        state = {}
+        if self._step > 0:
+            for a in self._arenas:
+                if a is None:
+                    continue
+                for p, o in zip(a["params"], a["offs"]):
+                    n = p.numel()
+                    state[index[id(p)]] = {"step": torch.tensor(float(self._step)),
+                                           "exp_avg": a["m"][o:o + n].view(p.shape).clone(),
+                                           "exp_avg_sq": a["v"][o:o + n].view(p.shape).clone()}
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        extra = sd.pop("hip", None)
-        super().load_state_dict(sd)
-        if extra is not None:
-            if not self._built:
-                self._build()
-            self._step = extra["step"]
-            for a, m, v in zip(self._arenas, extra["m"], extra["v"]):
-                if a is not None:
-                    a["m"].copy_(m)
-                    a["v"].copy_(v)
+        """Accepts a torch.optim.Adam/AdamW state dict (what the reference's save_model writes) or one of ours (same
+        format).  The caller's dict is not modified."""
+        if not self._built:
+            self._build()
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        for mine, theirs in zip(self.param_groups, groups):
+            if len(mine["params"]) != len(theirs["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of "
+                                 "optimizer's group")
+            if theirs.get("amsgrad") or theirs.get("maximize"):
+                raise NotImplementedError("amsgrad / maximize state cannot be continued by the fused HIP step")
+            for k in ("lr", "betas", "eps", "weight_decay", "decoupled_weight_decay"):
+                if k in theirs:
+                    mine[k] = theirs[k]
+        # saved index -> my parameter, group by group in order (torch's own mapping rule)
+        by_saved = {}
+        for mine, theirs in zip(self.param_groups, groups):
+            for p, i in zip(mine["params"], theirs["params"]):
+                by_saved[i] = p
+        slot = {}
+        for a in self._arenas:
+            if a is not None:
+                for p, o in zip(a["params"], a["offs"]):
+                    slot[id(p)] = (a, o)
+        steps = set()
+        for a in self._arenas:
+            if a is not None:
+                a["m"].zero_()
+                a["v"].zero_()
+        for i, st in sd["state"].items():
+            p = by_saved.get(int(i))
+            if p is None:
+                raise ValueError(f"state for unknown parameter index {i}")
+            if id(p) not in slot:
+                continue                                   # state of a parameter this path never updates
+            a, o = slot[id(p)]
+            n = p.numel()
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"exp_avg of parameter {i} has shape {tuple(st['exp_avg'].shape)}, expected {tuple(p.shape)}")
+            a["m"][o:o + n].view(p.shape).copy_(st["exp_avg"])
+            a["v"][o:o + n].view(p.shape).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"parameters carry different step counts {sorted(steps)}; the fused step keeps one")
+        self._step = steps.pop() if steps else 0
 
 
 class GradSync:
-    """Data-parallel gradient averaging over RCCL (`backend="nccl"` is RCCL on ROCm): all-reduce(avg) of slices of the
-    flat gradient arenas.  Replaces DistributedDataParallel's per-bucket copies (reference CTClipTrainer.py:62-69,109-115).
+    """Data-parallel gradient averaging over RCCL (`backend="nccl"` is RCCL on ROCm): all-reduce(avg) of contiguous slices
+    ("buckets") of the flat gradient arenas.  Replaces DistributedDataParallel's per-bucket copies (reference
+    CTClipTrainer.py:62-69,109-115; fired from :196).
 
-    With 7 xGMI peers a few large collectives keep every link busy; bucket_mb sizes the slices so the first ones
-    (issued as soon as backward ends) overlap with the rest of the host-side step."""
+    Overlap with backward: every parameter reports once per step when its gradient has been ISSUED into the arena --
+    through `ops.grad_ready_hook` from the Functions that accumulate in place, through a post-accumulate hook for
+    gradients autograd delivers.  A bucket whose parameters have all reported is all-reduced at once, so buckets leave in
+    reverse-autograd order while the rest of backward runs.  Gradient kernels run on two streams (weight gradients on
+    ops' side stream), so the collective is issued from the side stream after it has been made to wait for the main
+    stream: RCCL's stream then orders after everything issued on either.  Whatever has not reported when backward
+    returns is reduced by all_reduce_grads().  With 7 xGMI peers a few large collectives keep every link busy;
+    `bucket_mb` sizes them."""
 
-    def __init__(self, optimizer: HipAdam, bucket_mb: int = 128, group=None, overlap: bool = True):
+    def __init__(self, optimizer: HipAdam, bucket_mb: int = 64, group=None, overlap: bool = True):
         self.opt, self.group = optimizer, group
-        self.bucket_elems = bucket_mb * (1 << 20) // 4
-        self._early = []            # (arena index, start, stop, work handle or (handle, chunk)) launched during backward
+        self.bucket_elems = max(1, bucket_mb * (1 << 20) // 4)
+        self.overlap = overlap
+        self._buckets = None        # list of dict(ai, start, stop, n, pending, handle)
+        self._bucket_of = {}
+        self._hooks = []
         if overlap:
-            from . import ops
-            ops.grad_ready_hook = self.early_reduce
+            ops.grad_ready_hook = self.param_ready
 
-    def _launch(self, chunk):
-        w = self.world()
-        if chunk.is_cuda and dist.get_backend(self.group) == "nccl":
-            return dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-        return (dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk)
-
-    def early_reduce(self, param):
-        """Called from a backward once `param`'s gradient kernels have been issued: start its all-reduce now, on RCCL's
-        stream (which first waits for the work already queued on the compute stream), and remember the slice."""
-        if self.world() == 1 or not self.opt._built:
-            return
-        for ai, a in enumerate(self.opt._arenas):
-            if a is None:
-                continue
-            for p, o in zip(a["params"], a["offs"]):
-                if p is param:
-                    start, stop = o, o + p.numel()
-                    self._early.append((ai, start, stop, self._launch(a["g"][start:stop])))
-                    return
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if ops.grad_ready_hook == self.param_ready:
+            ops.grad_ready_hook = None
 
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def all_reduce_grads(self):
-        w = self.world()
-        if w == 1:
+    def active(self) -> bool:
+        """Collectives run whenever a process group exists -- also at world size 1, where they are no-ops on the data but
+        the RCCL path is the one exercised."""
+        return dist.is_available() and dist.is_initialized()
+
+    # -- plan ---------------------------------------------------------------------------------------------------
+    def _plan(self):
+        arenas = getattr(self.opt, "_arenas", None)
+        self._buckets, self._bucket_of = [], {}
+        if arenas is None:                                   # arena-less stand-in (CPU tests): fixed-size slices
+            for ai, g in enumerate(self.opt.flat_grads()):
+                for s in range(0, g.numel(), self.bucket_elems):
+                    self._buckets.append(dict(ai=ai, start=s, stop=min(g.numel(), s + self.bucket_elems), n=0,
+                                              pending=0, handle=None))
             return
-        handles = [e[3] for e in self._early]
-        arenas = [a for a in getattr(self.opt, "_arenas", []) if a is not None] if hasattr(self.opt, "_arenas") else None
-        grads = self.opt.flat_grads()
-        for gi, g in enumerate(grads):
-            n = g.numel()
-            # slices not already in flight: the gaps around the early-reduced ranges of this arena
-            done = sorted((s0, s1) for (ai, s0, s1, _) in self._early
-                          if arenas is not None and arenas[gi] is self.opt._arenas[ai])
-            pos = 0
-            gaps = []
-            for s0, s1 in done:
-                if s0 > pos:
-                    gaps.append((pos, s0))
-                pos = max(pos, s1)
-            if pos < n:
-                gaps.append((pos, n))
-            for g0, g1 in gaps:
-                for s in range(g0, g1, self.bucket_elems):
-                    handles.append(self._launch(g[s:min(g1, s + self.bucket_elems)]))
-        self._early = []
-        for h in handles:
+        if not self.opt._built:
+            self.opt._build()
+        for ai, a in enumerate(arenas):
+            if a is None:
+                continue
+            cur = None
+            total = a["g"].numel()
+            for i, (p, o) in enumerate(zip(a["params"], a["offs"])):
+                if cur is not None and p.numel() >= self.bucket_elems:
+                    cur = None                               # a tensor that fills a bucket by itself travels alone: it
+                                                             # must not wait for small neighbours that finish much later
+                if cur is None:
+                    cur = dict(ai=ai, start=o, stop=o, n=0, pending=0, handle=None)
+                    self._buckets.append(cur)
+                cur["n"] += 1
+                cur["stop"] = a["offs"][i + 1] if i + 1 < len(a["offs"]) else total
+                self._bucket_of[id(p)] = cur
+                if cur["stop"] - cur["start"] >= self.bucket_elems:
+                    cur = None
+                if self.overlap and hasattr(p, "register_post_accumulate_grad_hook"):
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self.param_ready))
+        for b in self._buckets:
+            b["pending"] = b["n"]
+
+    def _flat(self, b):
+        arenas = getattr(self.opt, "_arenas", None)
+        g = arenas[b["ai"]]["g"] if arenas is not None else self.opt.flat_grads()[b["ai"]]
+        return g[b["start"]:b["stop"]]
+
+    # -- launch -------------------------------------------------------------------------------------------------
+    def _launch(self, b):
+        chunk = self._flat(b)
+        if chunk.is_cuda and dist.get_backend(self.group) == "nccl":
+            side = ops.side_stream_for_collectives()
+            if side is None:
+                b["handle"] = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            else:
+                # gradient kernels were issued on the main AND the side stream: side waits for main's tail, the
+                # collective is issued from side, so RCCL's stream orders after both
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    b["handle"] = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        else:                                                # gloo: no AVG
+            b["handle"] = (dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk)
+
+    def param_ready(self, param):
+        """`param`'s gradient kernels have been issued (once per parameter per step)."""
+        if not self.active():
+            return
+        if self._buckets is None:
+            self._plan()
+        b = self._bucket_of.get(id(param))
+        if b is None or b["handle"] is not None:
+            return
+        b["pending"] -= 1
+        if b["pending"] <= 0:
+            self._launch(b)
+
+    # kept for callers of the round-1 name
+    early_reduce = param_ready
+
+    def all_reduce_grads(self):
+        """Reduce what is left, wait for everything (the current stream then orders after RCCL's), reset for the next step."""
+        if not self.active():
+            return
+        if self._buckets is None:
+            self._plan()
+        w = self.world()
+        for b in self._buckets:
+            if b["handle"] is None:
+                self._launch(b)
+        for b in self._buckets:
+            h = b["handle"]
             if isinstance(h, tuple):
                 h[0].wait()
                 h[1].div_(w)
             else:
                 h.wait()
+            b["handle"] = None
+            b["pending"] = b["n"]

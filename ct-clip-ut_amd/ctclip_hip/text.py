@@ -46,6 +46,7 @@ class BertEmbedFn(Function):
         return y
 
     @staticmethod
+    @ops.announces
     def backward(ctx, dy):
         ids, tt, e, mean, rstd, lnw = ctx.saved_tensors
         B, L, Hd, nw, npos, nt = ctx.dims
@@ -132,6 +133,7 @@ class BertLayerFn(Function):
         return x2
 
     @staticmethod
+    @ops.announces
     def backward(ctx, dy):
         xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, l1w, l2w, mask_add = ctx.saved_tensors
         sh = ctx.sh

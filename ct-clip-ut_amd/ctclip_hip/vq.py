@@ -42,6 +42,7 @@ class VectorQuantize(nn.Module):
         # searched, so parity tests can separate continuous arithmetic from discrete near-tie flips.
         self.forced_indices = None
         self.last_indices = None
+        self._pending_ema = None     # (work handle | None, bins, esum) of a codebook update whose all-reduce is in flight
 
     def _embed16(self):
         e = self._codebook.embed
@@ -53,6 +54,7 @@ class VectorQuantize(nn.Module):
             raise RuntimeError("VectorQuantize: MI355X HIP path only (no CPU fallback)")
         if self.dim % 8:
             raise ValueError("VectorQuantize: dim must be a multiple of 8")
+        self.flush_ema()
         cb = self._codebook
         embed = cb.embed[0]
         quant, idx = ops.VQFn.apply(x.to(F32), embed, self._embed16(), self.forced_indices)
@@ -60,13 +62,37 @@ class VectorQuantize(nn.Module):
         if self.training and not freeze_codebook:
             fn = quant.grad_fn
             x2, inv = (fn.aux if fn is not None and hasattr(fn, "aux") else _renorm(x))
-            reduce_fn = None
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                reduce_fn = lambda t: dist.all_reduce(t)          # library syncs bins / embed_sum
             with torch.no_grad():
-                ops.vq_ema_update(x2, inv, idx, cb.embed, cb.cluster_size, cb.decay, reduce_fn)
-                cb.embed.add_(0)                                   # bump the version: bf16 shadow is stale
+                bins, esum, flat = ops.vq_ema_accum(x2, inv, idx, self.codebook_size, self.dim)
+                handle = None
+                if dist.is_available() and dist.is_initialized():
+                    # the library all-reduces bins and embed_sum.  Here: ONE collective over the flat buffer
+                    # that holds both, asynchronous -- nothing reads the new codebook before the next forward, so the
+                    # 16.8 MB exchange runs under the rest of this step (flush_ema() joins it)
+                    handle = dist.all_reduce(flat, async_op=True)
+                self._pending_ema = (handle, bins, esum)
+                if handle is None:
+                    self.flush_ema()
         return quant, idx, torch.zeros((), device=x.device)
+
+    def flush_ema(self):
+        """Apply a codebook update whose statistics were (all-)reduced in the background.  Called at the start of the
+        next forward and by the trainer at the end of a step, so buffers read in between are always up to date."""
+        pend = self._pending_ema
+        if pend is None:
+            return
+        self._pending_ema = None
+        handle, bins, esum = pend
+        if handle is not None:
+            handle.wait()                                          # the current stream now orders after RCCL's
+        cb = self._codebook
+        with torch.no_grad():
+            ops.vq_ema_apply(cb.embed, cb.cluster_size, bins, esum, cb.decay)
+            cb.embed.add_(0)                                       # bump the version: bf16 shadow is stale
+
+    def state_dict(self, *args, **kwargs):
+        self.flush_ema()
+        return super().state_dict(*args, **kwargs)
 
 
 def _renorm(x):

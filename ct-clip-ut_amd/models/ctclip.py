@@ -21,8 +21,6 @@ class GatherWithGrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tensor):
         world = dist.get_world_size()
-        if world == 1:
-            return tensor
         t = tensor.contiguous()
         out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         if t.is_cuda and dist.get_backend() == "nccl":
@@ -35,8 +33,6 @@ class GatherWithGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         world = dist.get_world_size()
-        if world == 1:
-            return grad_output
         return grad_output.chunk(world, dim=0)[dist.get_rank()].contiguous()
 
 
@@ -87,7 +83,13 @@ class CTCLIP(nn.Module):
         text_latents = ops.LinearF32Fn.apply(text_output.to(F32), self.to_text_latent.weight, None, False)  # :115
         text_latents = ops.RowNormFn.apply(text_latents)                                      # :119
         image_latents = ops.RowNormFn.apply(image_latents)                                    # :120
-        text_latents = self.gather_features(text_latents)                                     # :123
-        image_latents = self.gather_features(image_latents)                                   # :124
+        if self.gather_negatives and dist.is_available() and dist.is_initialized():
+            # :123-124 as ONE collective: the reference gathers text then image latents with two all_gathers; both are
+            # [B, dim_latent] and latency-bound, so they travel side by side in one [B, 2*dim_latent] buffer.  Row r of
+            # the gathered buffer is still rank-major pair r, and GatherWithGrad's backward (local slice, no reduce)
+            # acts on rows, so values and gradients are those of the two separate calls.
+            L = text_latents.shape[1]
+            both = GatherWithGrad.apply(torch.cat((text_latents, image_latents), dim=1))
+            text_latents, image_latents = both[:, :L].contiguous(), both[:, L:].contiguous()
         sim = ops.SimMatrixFn.apply(image_latents, text_latents, self.temperature)            # :127
         return sim, image_latents, text_latents, self.temperature.exp(), image_tokens

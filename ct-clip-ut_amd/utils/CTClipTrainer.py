@@ -25,7 +25,7 @@ import torch.distributed as dist
 from torch import nn
 
 from ctclip_hip import ops
-from ctclip_hip.optim import GradSync
+from ctclip_hip.optim import GradSync, mark_unused
 from models.ctclip import CTCLIP
 from utils.optimizer import get_optimizer
 
@@ -87,9 +87,13 @@ class CTClipTrainer(nn.Module):
         self.max_grad_norm, self.save_best_model = max_grad_norm, save_best_model
         self.train_dl, self.valid_dl = train_dl, valid_dl
 
-        trainable = [p for n, p in self.model.named_parameters()
-                     if p.requires_grad and not any(tag in n for tag in STATICALLY_UNUSED)]
-        self.optim = get_optimizer(trainable, lr=lr, wd=wd)                    # reference :107
+        # every parameter goes to the optimiser, as in the reference (:107), so the parameter indices of an "optim"
+        # checkpoint are interchangeable; the statically unused ones are tagged and get no arena slot / Adam state
+        # (torch's Adam creates none for a parameter whose grad stays None either)
+        for n, p in self.model.named_parameters():
+            if any(tag in n for tag in STATICALLY_UNUSED):
+                mark_unused(p)
+        self.optim = get_optimizer(self.model.parameters(), lr=lr, wd=wd)      # reference :107
         self.grad_sync = GradSync(self.optim)
         if self.accelerator.distributed:                                       # DDP broadcasts rank-0 weights at wrap time
             for t in list(self.model.parameters()) + list(self.model.buffers()):
@@ -138,10 +142,11 @@ class CTClipTrainer(nn.Module):
 
     # ---- loss bookkeeping (reference :156-175) -----------------------------------------------------------------
     def avg_device_loss(self, loss):
-        t = torch.tensor(float(loss), device=self.accelerator.device)
-        if self.accelerator.distributed:
+        """Mean of a per-rank scalar over the ranks (reference :156-162: gather_for_metrics + mean), as a python float."""
+        t = torch.as_tensor(float(loss), dtype=torch.float32, device=self.accelerator.device)
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            t = t / self.accelerator.num_processes
+            t = t / dist.get_world_size()
         return t.item()
 
     def loss_function(self, sim_matrix, targets=None):
@@ -172,6 +177,9 @@ class CTClipTrainer(nn.Module):
         loss.backward()
         self.grad_sync.all_reduce_grads()
         self.optim.step(max_grad_norm=self.max_grad_norm if self.max_grad_norm else None)
+        vq = getattr(getattr(self.model, "visual_transformer", None), "vq", None)
+        if hasattr(vq, "flush_ema"):
+            vq.flush_ema()                      # codebook statistics were all-reduced under the backward pass
         self.global_step += 1
         return loss.detach() if return_tensor else loss.item()
 
@@ -195,25 +203,44 @@ class CTClipTrainer(nn.Module):
         return avg
 
     def train(self):
+        """Reference :252-304: epochs of train_step + per-step averaged loss, evaluate(0) after the very first step and
+        evaluate(epoch) after every epoch (which saves `best_checkpoint.pt` as the reference does, :238-244)."""
         if self.train_dl is None:
             raise RuntimeError("no training data: pass train_dl=")
         start = time.time()
+        n_batches = len(self.train_dl) if hasattr(self.train_dl, "__len__") else None
+        save_at = max(1, n_batches // self.num_save_split) if n_batches else 1                  # reference :257
+        self.maybe_print("Training started")
+        durations = []
         for epoch in range(1, self.num_epochs + 1):
             t0 = time.time()
+            self.maybe_print(f"\nStarting Epoch {epoch}/{self.num_epochs}")
+            sampler = getattr(self.train_dl, "sampler", None)
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)                                                         # reference :265
             total, steps = 0.0, 0
             for step, batch in enumerate(self.train_dl, start=1):
                 loss = self.train_step(batch)
                 total += loss
                 steps += 1
-                avg_step = self.avg_device_loss(loss)                          # reference :272
-                if epoch == 1 and step == 1:
+                avg_step = self.avg_device_loss(loss)                                            # reference :272
+                if step % save_at == 0:
+                    self.train_losses.setdefault("steps", []).append(avg_step)
+                if epoch == 1 and step == 1:                                                     # reference :278-281
                     self.train_losses.setdefault("epochs", []).append(avg_step)
+                    self.train_losses.setdefault("steps", []).append(avg_step)
                     self.evaluate(0)
-                self.train_losses.setdefault("steps", []).append(avg_step)
-                self.maybe_print(f"Epoch {epoch} | Step {step} | Avg Loss: {avg_step:.6f}")
+                of = f"/{n_batches}" if n_batches else ""
+                self.maybe_print(f"Epoch {epoch} | Step {step}{of} | Avg Loss: {avg_step:.6f}")
             avg_epoch = self.avg_device_loss(total / max(steps, 1))
             self.train_losses.setdefault("epochs", []).append(avg_epoch)
-            self.maybe_print(f"Epoch {epoch} completed. Average Loss: {avg_epoch:.6f} "
-                             f"({timedelta(seconds=time.time() - t0)})")
+            durations.append(time.time() - t0)
+            self.maybe_print(f"Epoch {epoch} completed. Average Loss: {avg_epoch:.6f}")
+            self.maybe_print(f"Time taken for Epoch {epoch}: {timedelta(seconds=durations[-1])}")
+            t1 = time.time()
             self.evaluate(epoch)
-        self.maybe_print(f"Training completed in {timedelta(seconds=time.time() - start)}")
+            self.maybe_print(f"Time taken for evaluation: {timedelta(seconds=time.time() - t1)}")
+        self.maybe_print("Training completed")
+        self.maybe_print(f"Total Training Time: {timedelta(seconds=time.time() - start)}")
+        if durations:
+            self.maybe_print(f"Average Epoch Duration: {timedelta(seconds=sum(durations) / len(durations))}")

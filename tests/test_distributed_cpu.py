@@ -90,38 +90,151 @@ def test_gradsync_bucketed_average():
     _run(_bucketed_allreduce)
 
 
-def _early_reduce_then_rest(rank):
-    """A parameter whose gradient is announced during backward is all-reduced early; all_reduce_grads() then covers exactly
-    the remaining gaps of the arena, so every element is averaged exactly once."""
-    from ctclip_hip.optim import GradSync
+def _hook_driven_buckets(rank):
+    """The real HipAdam arena (plumbing only, on CPU) + GradSync: parameters report as backward produces their gradients
+    -- autograd-delivered ones through the post-accumulate hook, in-place accumulating Functions through
+    ops.grad_slot()/announce_grads() -- and a bucket is all-reduced the moment its last parameter has reported, i.e.
+    in reverse-autograd order while backward is still running.  A tensor as large as a bucket travels alone.  Every
+    element is averaged exactly once."""
+    from ctclip_hip import ops
+    from ctclip_hip.optim import GradSync, HipAdam, mark_unused
+    torch.manual_seed(0)                                                       # same weights on both ranks
+    lin1, lin2, big = torch.nn.Linear(6, 5), torch.nn.Linear(5, 4), torch.nn.Linear(4, 64, bias=False)
+    unused = torch.nn.Parameter(torch.zeros(3))
+    mark_unused(unused)
+    direct = torch.nn.Parameter(torch.zeros(8))                                # gradient written in place by a "kernel"
+    params = [*lin1.parameters(), unused, *lin2.parameters(), *big.parameters(), direct]
+    # reference first (no hooks installed yet): the plain local gradients, to be averaged with a bare all-reduce
+    torch.manual_seed(10 + rank)                                               # different data per rank
+    x = torch.randn(3, 6)
+    y2 = big(lin2(torch.relu(lin1(x))))
+    (y2 ** 2).sum().backward()
+    want = {id(pr): pr.grad.clone() for pr in params if pr.grad is not None}
+    want[id(direct)] = (2 * y2.detach()).sum() * torch.arange(8.0) * (rank + 1)
+    for pr in params:
+        pr.grad = None
+    opt = HipAdam(params, lr=1e-3)
+    sync = GradSync(opt, bucket_mb=1)
+    sync.bucket_elems = 40                                                     # lin1 (36) + lin2.weight | lin2.bias.. | big alone
+    opt.zero_grad()
+    sync._plan()
+    ranges = [(b["start"], b["stop"], b["n"]) for b in sync._buckets]
+    big_off = next(o for pr, o in zip(opt._arenas[0]["params"], opt._arenas[0]["offs"]) if pr is big.weight)
+    assert (big_off, big_off + 256, 1) in ranges, ranges                      # the 256-element tensor has its own bucket
+    assert id(unused) not in sync._bucket_of
+    launched = []
+    real_launch = sync._launch
+    sync._launch = lambda b: (launched.append((b["start"], b["stop"])), real_launch(b))[1]
 
-    class Arena:
-        _built = True
+    class InPlace(torch.autograd.Function):                                    # stands in for a HIP backward
+        @staticmethod
+        def forward(ctx, x, p):
+            ctx.p = p
+            return x * 1.0
 
-        def __init__(self):
-            torch.manual_seed(100 + rank)
-            self.params = [torch.nn.Parameter(torch.zeros(n)) for n in (40, 300, 17)]
-            self.offs = [0, 40, 340]
-            self.g = torch.randn(360)
-            self._arenas = [None, dict(g=self.g, params=self.params, offs=self.offs)]
+        @staticmethod
+        @ops.announces
+        def backward(ctx, dy):
+            slot, is_direct = ops.grad_slot(ctx.p)
+            assert is_direct
+            slot += dy.sum() * torch.arange(8.0) * (rank + 1)
+            return dy, None
 
-        def flat_grads(self):
-            return [self.g]
-
-    ar = Arena()
-    everyone = [torch.zeros(360) for _ in range(WORLD)]
-    dist.all_gather(everyone, ar.g.clone())
-    sync = GradSync(ar, overlap=False)
-    sync.bucket_elems = 64
-    sync.early_reduce(ar.params[1])                                            # the middle slice goes first
-    assert len(sync._early) == 1 and sync._early[0][1:3] == (40, 340)
+    y = big(lin2(torch.relu(lin1(x))))
+    y = InPlace.apply(y, direct)
+    during = []
+    y.register_hook(lambda g: during.append(len(launched)))
+    (y ** 2).sum().backward()
+    n_early = len(launched)
+    assert n_early >= 2, launched                                              # buckets left while backward was running
+    assert launched[0][0] >= big_off                                          # reverse-autograd order: the tail of the arena first
     sync.all_reduce_grads()
-    torch.testing.assert_close(ar.g, sum(everyone) / WORLD)
-    assert sync._early == []
+    assert len(launched) == len(sync._buckets)
+    a = opt._arenas[0]
+    for pr, o in zip(a["params"], a["offs"]):
+        w = want[id(pr)].clone()
+        dist.all_reduce(w)
+        torch.testing.assert_close(a["g"][o:o + pr.numel()].view(pr.shape), w / WORLD, rtol=1e-5, atol=1e-6)
+    assert all(b["handle"] is None and b["pending"] == b["n"] for b in sync._buckets)   # armed for the next step
+    sync.close()
+    assert ops.grad_ready_hook is None
 
 
-def test_gradsync_early_slice_plus_gaps_average_once():
-    _run(_early_reduce_then_rest)
+def test_gradsync_buckets_leave_during_backward_and_average_once():
+    _run(_hook_driven_buckets)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _fused_latent_gather(rank):
+    """CTCLIP.forward gathers text and image latents with ONE collective over [B, 2L] (reference ctclip.py:123-124 uses two
+    all_gathers): values and gradients equal those of the two separate GatherWithGrad calls."""
+    from models.ctclip import GatherWithGrad
+    torch.manual_seed(5 + rank)
+    B, L = 3, 4
+    t = torch.randn(B, L, requires_grad=True)
+    i = torch.randn(B, L, requires_grad=True)
+    t2, i2 = t.detach().clone().requires_grad_(True), i.detach().clone().requires_grad_(True)
+    gt, gi = GatherWithGrad.apply(t), GatherWithGrad.apply(i)                  # the reference's two calls
+    both = GatherWithGrad.apply(torch.cat((t2, i2), dim=1))                    # the fused one
+    ft, fi = both[:, :L], both[:, L:]
+    assert torch.equal(ft, gt) and torch.equal(fi, gi)
+    w = torch.arange(float(WORLD * B * WORLD * B)).reshape(WORLD * B, WORLD * B)
+    ((gi @ gt.t()) * w).sum().backward()
+    ((fi @ ft.t()) * w).sum().backward()
+    torch.testing.assert_close(t2.grad, t.grad)
+    torch.testing.assert_close(i2.grad, i.grad)
+
+
+def test_fused_latent_gather_equals_two_gathers():
+    _run(_fused_latent_gather)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _avg_device_loss(rank):
+    """CTClipTrainer.avg_device_loss (reference CTClipTrainer.py:156-162): the mean over ranks, as a python float."""
+    from utils.CTClipTrainer import CTClipTrainer
+
+    class Stub:
+        class accelerator:
+            device = torch.device("cpu")
+
+    got = CTClipTrainer.avg_device_loss(Stub(), 1.0 + 2.0 * rank)
+    assert isinstance(got, float) and abs(got - sum(1.0 + 2.0 * r for r in range(WORLD)) / WORLD) < 1e-6
+    got = CTClipTrainer.avg_device_loss(Stub(), torch.tensor(3.0 * rank))
+    assert abs(got - 1.5 * (WORLD - 1)) < 1e-6
+
+
+def test_avg_device_loss_is_the_mean_over_ranks():
+    _run(_avg_device_loss)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _vq_ema_async(rank):
+    """the codebook statistics (bins, embed_sum) are summed over the ranks by ONE asynchronous collective over
+    the flat buffer that holds both; flush_ema() joins it and applies the update exactly once (the apply kernel is stood
+    in by a recorder here -- the wiring is what is tested)."""
+    from ctclip_hip import ops, vq as vqmod
+    q = vqmod.VectorQuantize(dim=8, codebook_size=16)
+    flat = torch.full((16 * 9,), float(rank + 1))
+    bins, esum = flat[:16], flat[16:].view(16, 8)
+    q._pending_ema = (dist.all_reduce(flat, async_op=True), bins, esum)
+    seen = []
+    real = ops.vq_ema_apply
+    ops.vq_ema_apply = lambda embed, cs, b, e, decay: seen.append((b.clone(), e.clone(), decay))
+    try:
+        q.flush_ema()
+        q.flush_ema()                                                          # nothing pending: no second apply
+        sd = q.state_dict()                                                    # flushes too (nothing pending)
+    finally:
+        ops.vq_ema_apply = real
+    total = float(sum(r + 1 for r in range(WORLD)))
+    assert len(seen) == 1 and seen[0][2] == 0.8
+    assert torch.all(seen[0][0] == total) and torch.all(seen[0][1] == total)
+    assert "_codebook.embed" in sd
+
+
+def test_vq_codebook_statistics_reduce_in_the_background():
+    _run(_vq_ema_async)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,107 @@
+"""GPU tests of the trainer surface beyond one step (reference src/utils/CTClipTrainer.py:206-304, src/train_ctclip.py:17-60)
+and of the RCCL code paths of the data-parallel design at world size 1: on one GPU the
+collectives move no data between ranks, but `backend="nccl"` IS RCCL on ROCm, so every branch that the 8-GPU run takes
+(`all_gather_into_tensor`, async AVG all-reduce of arena buckets issued from the weight-gradient stream during backward,
+the background codebook-statistics reduce, the loss average) executes here once and must leave the step's result unchanged.
+"""
+import math
+import os
+import runpy
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_example_script_trains_and_evaluates(tmp_path, monkeypatch, capsys):
+    """examples/train_ctclip_synthetic.py = the reference's train_ctclip.py with synthetic data: trainer.train() runs an
+    epoch of two steps, evaluate(0) after the first step and evaluate(1) after the epoch, best checkpoint saved."""
+    monkeypatch.setenv("CTCLIP_EXAMPLE_SMALL", "1")
+    monkeypatch.setenv("CTCLIP_EXAMPLE_RESULTS", str(tmp_path))
+    monkeypatch.setenv("CTCLIP_EXAMPLE_STEPS", "2")
+    monkeypatch.setenv("CTCLIP_EXAMPLE_EPOCHS", "1")
+    ns = runpy.run_path(os.path.join(ROOT, "examples", "train_ctclip_synthetic.py"), run_name="__main__")
+    trainer = ns["trainer"]
+    out = capsys.readouterr().out
+    assert "Training started" in out and "Epoch 1 | Step 2/2" in out and "Training completed" in out
+    assert trainer.global_step == 2
+    assert len(trainer.valid_losses) == 2 and all(math.isfinite(v) for v in trainer.valid_losses)    # evaluate(0), evaluate(1)
+    assert len(trainer.train_losses["epochs"]) == 2                     # first-step loss + the epoch average (reference :278-286)
+    assert len(trainer.train_losses["steps"]) >= 2
+    ckpt = trainer.results_folder / "best_checkpoint.pt"
+    assert ckpt.exists() and (trainer.results_folder / "architecture.txt").exists()
+    pkg = torch.load(ckpt, map_location="cpu", weights_only=False)
+    assert set(pkg["model"]) == set(trainer.model.state_dict())
+    # the optimiser entry is torch.optim.Adam's format over ALL model parameters, as the reference writes it
+    n_params = len(list(trainer.model.parameters()))
+    assert pkg["optim"]["param_groups"][0]["params"] == list(range(n_params))
+    st = next(iter(pkg["optim"]["state"].values()))
+    assert set(st) == {"step", "exp_avg", "exp_avg_sq"}
+    # evaluate() on its own, eval mode, no parameter change
+    before = {k: v.clone() for k, v in trainer.model.state_dict().items()}
+    v = trainer.evaluate(7)
+    assert math.isfinite(v) and len(trainer.valid_losses) == 3
+    for k, t in trainer.model.state_dict().items():
+        assert torch.equal(t, before[k]), k
+    # ... and the checkpoint loads into the REFERENCE's optimiser class (torch.optim.Adam over model.parameters())
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone()) for p in trainer.model.parameters()], lr=1.0)
+    ref_opt.load_state_dict(pkg["optim"])
+    assert ref_opt.param_groups[0]["lr"] == 1.25e-5 and ref_opt.param_groups[0]["betas"] == (0.9, 0.99)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_rccl_branches_run_at_world_size_one():
+    import torch.distributed as dist
+    from test_hip_model import _config1
+    from ctclip_hip import ops
+    from utils.CTClipTrainer import CTClipTrainer
+    # single-process result first
+    clip, data, _ = _config1()
+    trainer = CTClipTrainer(clip, batch_size=4, results_folder=None)
+    losses = [trainer.train_step((vol, txt)) for txt, vol in data]
+    ref_state = {k: v.detach().clone() for k, v in clip.state_dict().items()}
+    trainer.grad_sync.close()
+    assert not trainer.accelerator.distributed
+
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        clip2, data2, _ = _config1()
+        tr2 = CTClipTrainer(clip2, batch_size=4, results_folder=None)
+        assert tr2.accelerator.distributed and tr2.accelerator.num_processes == 1
+        sync = tr2.grad_sync
+        launched = []
+        real = sync._launch
+        sync._launch = lambda b: (launched.append((b["start"], b["stop"])), real(b))[1]
+        losses2 = []
+        for txt, vol in data2:
+            n0 = len(launched)
+            losses2.append(tr2.train_step((vol, txt)))
+            assert len(launched) - n0 == len(sync._buckets)              # every bucket reduced exactly once per step
+        assert sync._bucket_of and all(b["handle"] is None for b in sync._buckets)
+        assert tr2.model.visual_transformer.vq._pending_ema is None      # the background codebook reduce was joined
+        avg = tr2.avg_device_loss(losses2[-1])
+        assert abs(avg - losses2[-1]) < 1e-6
+        for a, b in zip(losses, losses2):
+            print(f"  loss single-process {a:.7f}  through RCCL {b:.7f}")
+            assert abs(a - b) <= 1e-3 * abs(a)                          # f32 atomics reorder sums, nothing else differs
+        worst = 0.0
+        for k, v in clip2.state_dict().items():
+            if v.is_floating_point() and v.numel():
+                worst = max(worst, float((v - ref_state[k]).abs().max() / (ref_state[k].abs().max() + 1e-12)))
+        print(f"  worst parameter deviation after two steps: {worst:.2e}")
+        assert worst <= 1e-3
+        sync.close()
+    finally:
+        dist.destroy_process_group()

@@ -100,14 +100,75 @@ def test_get_optimizer_groups_like_reference():
     from utils.optimizer import get_optimizer, separate_params_by_weight_decay
     ps = [torch.nn.Parameter(torch.zeros(3, 3)), torch.nn.Parameter(torch.zeros(3)), torch.nn.Parameter(torch.zeros(2, 2, 2))]
     o = get_optimizer(ps, lr=1e-3, wd=0.0)
-    assert len(o.param_groups) == 1 and o.param_groups[0]["betas"] == (0.9, 0.99) and not o.param_groups[0]["decoupled"]
+    assert len(o.param_groups) == 1 and o.param_groups[0]["betas"] == (0.9, 0.99)
+    assert not o.param_groups[0]["decoupled_weight_decay"]
     o = get_optimizer(ps, lr=1e-3, wd=0.01)
     assert [len(g["params"]) for g in o.param_groups] == [2, 1]
-    assert [g["weight_decay"] for g in o.param_groups] == [0.01, 0.0] and all(g["decoupled"] for g in o.param_groups)
+    assert [g["weight_decay"] for g in o.param_groups] == [0.01, 0.0]
+    assert all(g["decoupled_weight_decay"] for g in o.param_groups)
     wd, nwd = separate_params_by_weight_decay(ps)
     assert len(wd) == 2 and len(nwd) == 1
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         o.step()
+    # the group keys are torch.optim.Adam's, so an exported state dict loads into the reference's optimiser
+    ref = torch.optim.AdamW([{"params": wd}, {"params": nwd, "weight_decay": 0}], lr=1e-3, weight_decay=0.01)
+    assert set(ref.param_groups[0]) == set(o.param_groups[0])
+
+
+def test_optimizer_state_dict_interchanges_with_torch_adam():
+    """reference CTClipTrainer.py:136-154 saves `optim.state_dict()` of torch.optim.Adam over model.parameters().
+    HipAdam reads and writes that format: per-parameter step / exp_avg / exp_avg_sq keyed by the parameter's index in
+    the FULL parameter list (statically unused parameters keep their index and carry no state, exactly like a torch
+    Adam parameter whose grad stays None).  Arena plumbing only -- no HIP kernel runs here."""
+    import copy
+    from ctclip_hip.optim import HipAdam, mark_unused
+    torch.manual_seed(0)
+    shapes = [(4, 3), (5,), (2, 2, 2), (7,)]
+    ref_ps = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    ref = torch.optim.Adam(ref_ps, lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    for _ in range(2):
+        for i, p in enumerate(ref_ps):
+            p.grad = None if i == 1 else torch.randn(p.shape)             # parameter 1 never gets a gradient
+        ref.step()
+    sd = ref.state_dict()
+    assert set(sd["state"]) == {0, 2, 3}
+    mine_ps = [torch.nn.Parameter(p.detach().clone()) for p in ref_ps]
+    mark_unused(mine_ps[1])
+    mine = HipAdam(mine_ps, lr=5e-1, betas=(0.5, 0.5), eps=1e-3)
+    frozen = copy.deepcopy(sd)
+    mine.load_state_dict(sd)
+    assert set(sd) == set(frozen) and set(sd["state"]) == set(frozen["state"])      # the caller's dict is untouched
+    g = mine.param_groups[0]
+    assert (g["lr"], g["betas"], g["eps"]) == (1e-2, (0.9, 0.99), 1e-8) and mine._step == 2
+    a = mine._arenas[0]
+    assert [id(p) for p in a["params"]] == [id(mine_ps[i]) for i in (0, 2, 3)]        # no slot for the unused one
+    for p, o in zip(a["params"], a["offs"]):
+        i = [id(q) for q in mine_ps].index(id(p))
+        torch.testing.assert_close(a["m"][o:o + p.numel()].view(p.shape), sd["state"][i]["exp_avg"])
+        torch.testing.assert_close(a["v"][o:o + p.numel()].view(p.shape), sd["state"][i]["exp_avg_sq"])
+    # and back: what HipAdam writes loads into a fresh torch Adam, which then continues from step 2
+    out = mine.state_dict()
+    assert set(out["state"]) == {0, 2, 3} and out["param_groups"][0]["params"] == [0, 1, 2, 3]
+    ref2_ps = [torch.nn.Parameter(p.detach().clone()) for p in ref_ps]
+    ref2 = torch.optim.Adam(ref2_ps, lr=1.0)
+    ref2.load_state_dict(out)
+    assert ref2.param_groups[0]["lr"] == 1e-2
+    grads = [torch.randn(s) for s in shapes]
+    for opt, ps in ((ref, ref_ps), (ref2, ref2_ps)):
+        for p, gr in zip(ps, grads):
+            p.grad = gr.clone()
+        opt.step()
+    for a_, b_ in zip(ref_ps, ref2_ps):
+        torch.testing.assert_close(a_.detach(), b_.detach())
+    # mismatching group sizes are rejected like torch does
+    with pytest.raises(ValueError):
+        HipAdam(mine_ps[:2], lr=1e-3).load_state_dict(sd)
+    # a gradient assigned as a NEW tensor (the torch.optim contract) is adopted into the arena before the step
+    mine.zero_grad()
+    new = torch.randn(4, 3)
+    mine_ps[0].grad = new.clone()
+    mine._bind_grads(adopt=True)
+    assert mine_ps[0].grad.data_ptr() == a["g"].data_ptr() and torch.equal(mine_ps[0].grad, new)
 
 
 def test_unsupported_branches_fail_loudly():
