@@ -12,7 +12,10 @@ Rules (see DESIGN.md "Oracle"):
   * It is pinned against the reference itself: `tests/golden/make_golden.py` imports the
     reference modules in the build container, runs them on seeded inputs and stores
     inputs + outputs under `tests/golden/*.npz`; `tests/test_oracle_golden.py` replays
-    those vectors through this file.  Two pieces are *parity unpinned* because their
+    those vectors through this file -- including the volume ingest (`preprocess_*`, pinned by the reference's own
+    `resize_array` / `crop_and_pad` / `process_file` run behind a `nibabel` stand-in) and the attribution loops
+    (`occlusion_heatmap`, `integrated_gradients`, pinned by the reference's own `Visualizations._compute_occlusion` /
+    `visualize_integrated_gradients` run through a stand-in `self`).  Two pieces are *parity unpinned* because their
     arithmetic lives in third-party packages that are absent from /root/reference and
     from the image:
       - vector-quantize-pytorch (lucidrains; version not pinned by the reference, call sites

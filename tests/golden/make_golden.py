@@ -306,10 +306,124 @@ def optimizer():
     save("optimizer.npz", **out)
 
 
+# ---- F. volume ingest (reference src/utils/preprocess.py) ------------------------------------
+def preprocess():
+    """`nibabel` is not installed; preprocess.py:3 imports it only for `nib.load(path).get_fdata()` (:12-14).  A stand-in
+    module whose load() hands back arrays registered here lets the reference's own `process_file`, `resize_array` and
+    `crop_and_pad` run unmodified on synthetic scans."""
+    import pandas as pd
+    scans = {}
+
+    class _Img:
+        def __init__(self, a):
+            self.a = a
+
+        def get_fdata(self):
+            return self.a
+
+    nb = types.ModuleType("nibabel")
+    nb.load = lambda path: _Img(scans[str(path)])
+    sys.modules["nibabel"] = nb
+    from utils import preprocess as RP  # noqa: E402  (reference)
+
+    g = torch.Generator().manual_seed(71)
+    out = {}
+    # resize_array (:20-37) and crop_and_pad (:38-82) directly, crop / pad / identity on different axes
+    for i, (shape, cur, tgt) in enumerate([((9, 14, 11), (2.0, 0.9, 0.9), (1.5, 0.75, 0.75)),
+                                            ((12, 10, 16), (1.0, 0.6, 0.6), (1.5, 0.75, 0.75)),
+                                            ((8, 8, 8), (1.5, 0.75, 0.75), (1.5, 0.75, 0.75))]):
+        x = torch.randn(1, 1, *shape, generator=g)
+        out[f"resize{i}.x"], out[f"resize{i}.cur"], out[f"resize{i}.tgt"] = x, np.array(cur), np.array(tgt)
+        out[f"resize{i}.y"] = RP.resize_array(x, cur, tgt)
+    for i, (shape, tgt) in enumerate([((10, 7, 12), (6, 11, 12)), ((5, 9, 4), (8, 4, 9)), ((6, 6, 6), (6, 6, 6)),
+                                      ((7, 8, 9), (4, 5, 6)), ((3, 4, 5), (8, 9, 10))]):
+        x = torch.randn(*shape, generator=g)
+        out[f"crop{i}.x"], out[f"crop{i}.tgt"] = x, np.array(tgt)
+        out[f"crop{i}.y"] = RP.crop_and_pad(x, tgt, pad_value=-1)
+    # the whole process_file pipeline (:84-157) for model_type "ctclip": target 480 x 480 x 240 is hard-coded there, so the
+    # output is [1, 240, 480, 480]; only its non-pad box is stored (everything outside it is the pad value -1, asserted)
+    for i, (hwd, xy, z, slope, icpt) in enumerate([((40, 36, 20), 1.0, 2.0, 1.0, -1024.0),
+                                                   ((30, 50, 24), 0.6, 1.2, 2.0, -2048.0)]):
+        raw = torch.randint(-200, 3000, hwd, generator=g).double().numpy()
+        name = f"scan{i}.nii.gz"
+        scans[f"/fake/{name}"] = raw
+        df = pd.DataFrame({"VolumeName": [name], "RescaleSlope": [slope], "RescaleIntercept": [icpt],
+                           "XYSpacing": [f"[{xy}, {xy}]"], "ZSpacing": [z]})
+        y = RP.process_file(f"/fake/{name}", name, df, "ctclip")
+        assert tuple(y.shape) == (1, 240, 480, 480)
+        nz = (y[0] != -1).nonzero()
+        lo, hi = nz.min(0).values, nz.max(0).values + 1
+        box = y[0, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        masked = y.clone()
+        masked[0, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = -1
+        assert bool((masked == -1).all())
+        out[f"file{i}.raw"] = raw.astype(np.float32)
+        out[f"file{i}.meta"] = np.array([slope, icpt, xy, z])
+        out[f"file{i}.lo"], out[f"file{i}.hi"], out[f"file{i}.box"] = lo, hi, box
+    save("preprocess.npz", **out)
+
+
+# ---- G. attribution loops (reference src/utils/visualizations.py) ----------------------------
+def attribution():
+    """`Visualizations._compute_occlusion` (:335-424) and the numeric part of `visualize_integrated_gradients` (:851-898)
+    run as the reference wrote them, on the reference CTCLIP (tiny, CPU), through a stand-in `self` that supplies only what
+    those two methods read (model, rank, world_size, accelerator.device / is_main_process; GIF rendering and result
+    directories stubbed out).  Importing the module seeds the global RNGs and switches deterministic algorithms on
+    (:29-39); the latter is switched back off afterwards."""
+    import tempfile
+    from pathlib import Path
+    if "nibabel" not in sys.modules:
+        sys.modules["nibabel"] = types.ModuleType("nibabel")
+    from utils import visualizations as RV  # noqa: E402  (reference)
+    torch.use_deterministic_algorithms(False)
+
+    g = torch.Generator().manual_seed(83)
+    torch.manual_seed(83)
+    vit_cfg = dict(dim=32, codebook_size=512, image_size=16, patch_size=4, temporal_patch_size=2, spatial_depth=1,
+                   temporal_depth=1, dim_head=8, heads=4)     # 6 x 4 x 4 tokens, 512 codes: occlusions do move codes
+    text = BertModel(BertConfig(**BERT_CFG)).eval()
+    randomize(text, g)
+    vit = RefCTViT(**vit_cfg)
+    randomize(vit, g)
+    enable_cpb_on_cpu(vit.spatial_rel_pos_bias, vit.patch_height, vit.patch_width)
+    clip = RefCTCLIP(text_encoder=text, image_encoder=vit, dim_text=BERT_CFG["hidden_size"], dim_image=4 * 4 * 32,
+                     dim_latent=16).eval()
+    image = (torch.randn(1, 1, 12, 16, 16, generator=g) * 0.5).clamp(-1, 1)
+    txt = text_batch(g, 1, 12, BERT_CFG["vocab_size"])
+    txt["attention_mask"][:] = 1
+    out = sd(clip)
+    out.update({"image": image, **{f"txt.{k}": v for k, v in txt.items()}})
+
+    tmp = Path(tempfile.mkdtemp())
+
+    class Acc:
+        device = torch.device("cpu")
+        is_main_process = True
+
+    class Self:                                          # what the two methods read from `self`
+        model, accelerator, rank, world_size = clip, Acc(), 0, 1
+
+        def _results_subdirectory(self, name):
+            return tmp
+
+        def visualize_overlay(self, *a, **k):
+            pass
+
+    patch, stride, thr = (4, 8, 8), (4, 4, 8), 0.2          # 3 x 3 x 2 = 18 windows, overlapping along h
+    hm = RV.Visualizations._compute_occlusion(Self(), image, txt, None, patch, stride, thr)
+    assert float((hm > 0).mean()) > 0.2, "degenerate occlusion fixture: no window moved the score"
+    out.update({"occ.patch": np.array(patch), "occ.stride": np.array(stride), "occ.threshold": np.array(thr),
+                "occ.heatmap": np.ascontiguousarray(hm)})
+    # two ranks: each returns nothing on rank != 0 before the reduce; only the window slicing is reference code worth
+    # pinning there, and it is covered by the single-process list above (ranks take contiguous equal slices, :352-362)
+    RV.Visualizations.visualize_integrated_gradients(Self(), image, txt, None, "scan", None, steps=5)
+    out["ig.steps"] = np.array(5)
+    out["ig.map"] = np.load(tmp / "scan.npy")
+    save("attribution.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    blocks()
-    ctvit()
-    bert()
-    ctclip()
-    optimizer()
+    which = sys.argv[1:] or ["blocks", "ctvit", "bert", "ctclip", "optimizer", "preprocess", "attribution"]
+    for name in which:
+        globals()[name]()

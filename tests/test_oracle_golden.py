@@ -184,3 +184,51 @@ def test_adam_matches_reference_factory():
             O.adam_step(b, g[f"{tag}.gb{s}"], mb, vb, s + 1, 1e-2, weight_decay=0.0)
             close(w, g[f"{tag}.w{s+1}"], rtol=1e-5, atol=1e-7)
             close(b, g[f"{tag}.b{s+1}"], rtol=1e-5, atol=1e-7)
+
+
+# ---- volume ingest and attribution loops, pinned by the reference's own functions -------------
+def test_preprocess_resize_crop_and_pipeline_match_reference():
+    """tests/golden/preprocess.npz: outputs of the reference's unmodified `resize_array`, `crop_and_pad` and `process_file`
+    (src/utils/preprocess.py:20-157, run behind a `nibabel` stand-in that serves synthetic scans)."""
+    g = load_golden("preprocess")
+    for i in range(3):
+        y = O.preprocess_resize_array(g[f"resize{i}.x"], tuple(g[f"resize{i}.cur"].tolist()), tuple(g[f"resize{i}.tgt"].tolist()))
+        assert tuple(y.shape) == tuple(g[f"resize{i}.y"].shape)
+        close(y, g[f"resize{i}.y"], rtol=1e-6, atol=1e-6)
+    for i in range(5):
+        y = O.preprocess_crop_and_pad(g[f"crop{i}.x"], tuple(int(v) for v in g[f"crop{i}.tgt"]), pad_value=-1)
+        assert torch.equal(y, g[f"crop{i}.y"])
+    for i in range(2):
+        slope, icpt, xy, z = (float(v) for v in g[f"file{i}.meta"])
+        y = O.preprocess_volume(g[f"file{i}.raw"], slope, icpt, xy, z)            # reference targets: 480 x 480 x 240
+        assert tuple(y.shape) == (1, 240, 480, 480)
+        lo, hi = g[f"file{i}.lo"], g[f"file{i}.hi"]
+        box = y[0, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        close(box, g[f"file{i}.box"], rtol=1e-6, atol=1e-6)
+        y[0, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = -1
+        assert bool((y == -1).all())                                               # everything else is the pad value
+
+
+ATTR_CFG = dict(dim=32, codebook_size=512, image_size=16, patch_size=4, temporal_patch_size=2, spatial_depth=1,
+                temporal_depth=1, dim_head=8, heads=4, text_layers=2, text_heads=4)
+
+
+def test_occlusion_and_integrated_gradients_match_reference_loops():
+    """tests/golden/attribution.npz: the reference's own `Visualizations._compute_occlusion` (window list, importance
+    accumulation, count normalisation, min-max, trilinear resize, threshold, rot90; src/utils/visualizations.py:335-424)
+    and the numeric part of `visualize_integrated_gradients` (:851-898) on the reference CTCLIP."""
+    import numpy as np
+    g = load_golden("attribution")
+    st = sub(g, "sd.")
+    txt = {k: g[f"txt.{k}"] for k in ("input_ids", "token_type_ids", "attention_mask")}
+    patch, stride = tuple(int(v) for v in g["occ.patch"]), tuple(int(v) for v in g["occ.stride"])
+    _, count, final = O.occlusion_heatmap(txt, g["image"], st, ATTR_CFG, patch, stride, float(g["occ.threshold"]))
+    ref = g["occ.heatmap"].numpy()
+    assert final.shape == ref.shape and float(count.max()) == 2.0
+    assert np.abs(final - ref).max() <= 2e-4, np.abs(final - ref).max()
+    assert ((final == 0) == (ref == 0)).mean() >= 0.999                            # same thresholded support
+    _, ig = O.integrated_gradients(txt, g["image"], st, ATTR_CFG, steps=int(g["ig.steps"]))
+    ref = g["ig.map"].numpy()
+    assert ig.shape == ref.shape
+    assert ((ig > 0) == (ref > 0)).mean() >= 0.999                                 # the top-decile mask
+    assert np.abs(ig - ref).max() <= 2e-3                                          # ** 0.05 amplifies f32 round-off near 0
