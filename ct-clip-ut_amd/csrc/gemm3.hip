@@ -27,21 +27,35 @@ struct Args {
   float alpha;
   bf16_t* G; long ldg;                             // act == 2: gelu(gate) * value of the 64-column interleaved [val|gate] blocks
                                                    // act == 3: G = h (pre-activations, same blocks), overwritten with d(h)
+  int stagger, stagger_shift, stagger_limit;       // start-up delay (10 ns ticks) of the workgroups with bit `shift` of blockIdx set
 };
 
 // [256 rows][32 k] bf16 tile, 64-byte rows, 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128 phase
 // (16 consecutive rows, same logical chunk) hit 16 different bank groups
-__device__ __forceinline__ uint32_t tile_off(int r, int chunk) { return (uint32_t)(r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4)); }
+// Key = (-(r >> 2)) & 3 serves both fragment shapes: a 32x32x16 read (32 consecutive rows, one chunk per lane half) only
+// needs the four row quads of a 16-lane phase on different keys; a 16x16x32 read (16 rows x all four chunks, chunk =
+// lane >> 4) puts row quads {0, 3} with chunk c and {1, 2} with chunk c ^ 1 in one phase, and {k0, k3, 1 ^ k1, 1 ^ k2} =
+// {0, 1, 2, 3} for this key (the plain key r >> 2 collides there).
+__device__ __forceinline__ int swz_key(int r) { return (-(r >> 2)) & 3; }
+__device__ __forceinline__ uint32_t tile_off(int r, int chunk) { return (uint32_t)(r * 64 + ((chunk ^ swz_key(r)) << 4)); }
 
 __device__ __forceinline__ bf16x8 read_frag(const char* tile, int rbase, int s, int lane) {
   const int r = rbase + (lane & 31);
   return *(const bf16x8*)(tile + tile_off(r, 2 * s + (lane >> 5)));
 }
 
+// 16x16x32 operand fragment: lane l holds row rbase + (l & 15), k = 8 (l >> 4) .. + 7 of the 32-deep K-step
+__device__ __forceinline__ bf16x8 read_frag16(const char* tile, int rbase, int lane) {
+  return *(const bf16x8*)(tile + tile_off(rbase + (lane & 15), lane >> 4));
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // element offset (from the operand base, at k-tile 0) of the 16 bytes lane `lane` contributes to 1 KiB piece `p`
 // (rows 16p .. 16p+15, 4 chunks each) of the tile whose first row is r0; its LDS destination is piece_base + lane*16
 __device__ __forceinline__ long piece_src(int p, int lane, int r0, int R, long ld) {
-  const int r = 16 * p + (lane >> 2), pc = lane & 3, c = pc ^ ((r >> 2) & 3);
+  const int r = 16 * p + (lane >> 2), pc = lane & 3, c = pc ^ swz_key(r);
   int row = r0 + r;
   if (row >= R) row = R - 1;                       // masked in the epilogue
   return (long)row * ld + c * 8;
@@ -72,7 +86,10 @@ template <bool NT> __device__ __forceinline__ void st16f(void* p, float a, float
 // BN = 128: 4 waves (2 x 2), 3-stage ring of 24 KiB = 72 KiB, TWO workgroups per CU: vmcnt is an in-order counter, so a
 //           wave cannot see its next tile's LDS-DMAs complete before its own epilogue stores have drained to HBM; with two
 //           independent workgroups one computes while the other writes back and refills its ring.
-template <int BN, int NS, bool NTS>
+// M16: the per-wave 128 x 64 tile as 8 x 4 MFMA 16x16x32 instead of 4 x 2 MFMA 32x32x16 -- the same LDS bytes, registers
+//      and matrix-pipe cycles per flop, but the part holds a higher clock on the smaller shape under load
+//      (MI355X_MICROARCH.md, DVFS give-back item 7).
+template <int BN, int NS, bool NTS, bool M16>
 __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
   constexpr int WN = BN / 64, NT = 2 * WN * 64;
   constexpr int STAGE = SUB + BN * BK * 2;
@@ -104,13 +121,31 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
     for (int j = j0; j < j0 + PPW / 2; ++j) G3_GLDS(src[j] + (long)t * BK, sb + dst[j]);
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][2];                                 // 32x32x16 form
+  f32x4 acc16[8][4];                                // 16x16x32 form (only one of the two is live in an instantiation)
+  if (M16) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+
+  if (g.stagger > 0 && ((blockIdx.x >> g.stagger_shift) & 1) && blockIdx.x < g.stagger_limit) {
+    // de-synchronise the two workgroups of a CU (BN = 128): they start together and do identical work, so they stay in
+    // lock-step -- both in the matrix loop, then both writing back.  Half a tile period of delay for the second one puts
+    // one workgroup's epilogue stores under the other's matrix loop; the pattern then carries itself through the grid.
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(8);
+  }
 
 #pragma unroll
   for (int t = 0; t < NS - 1; ++t)
@@ -131,18 +166,34 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
     const bool pre = t + NS - 1 < nk && !(g.act & 0x200);   // 0x200: timing experiment, no operand traffic after the prologue
     const char* sa = smem + (t % NS) * STAGE;
     const char* sb = sa + SUB;
+    if (M16) {
+      bf16x8 fa[8], fb[4];
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 fa[4], fb[2];
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag16(sb, wn * 64 + j * 16, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag(sa, wm * 128 + i * 32, s, lane);
+      for (int i = 0; i < 8; ++i) fa[i] = read_frag16(sa, wm * 128 + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = read_frag(sb, wn * 64 + j * 32, s, lane);
-      if (pre) issue_part(t + NS - 1, s * (PPW / 2));   // the next ring slot, half of the pieces between the MFMA groups
+      for (int h2 = 0; h2 < 2; ++h2) {
+        if (pre) issue_part(t + NS - 1, h2 * (PPW / 2));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 4 * h2; i < 4 * h2 + 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+          for (int j = 0; j < 4; ++j) acc16[i][j] = mfma16(fa[i], fb[j], acc16[i][j]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 fa[4], fb[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag(sa, wm * 128 + i * 32, s, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = read_frag(sb, wn * 64 + j * 32, s, lane);
+        if (pre) issue_part(t + NS - 1, s * (PPW / 2));   // the next ring slot, half of the pieces between the MFMA groups
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
+      }
     }
   }
 
@@ -154,12 +205,22 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
   for (int hh = 0; hh < 2; ++hh) {
     __syncthreads();                               // fragment reads of the last stage / the other half's stores are done
     if (wm == hh) {
+      if (M16) {                                   // acc16[i][j][r] = D[16 i + 4 (lane >> 4) + r][16 j + (lane & 15)]
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) ct[(i * 32 + acc_row(r, half)) * BN + wn * 64 + j * 32 + lc] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r)
+              ct[(i * 16 + 4 * (lane >> 4) + r) * BN + wn * 64 + j * 16 + (lane & 15)] = acc16[i][j][r];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ct[(i * 32 + acc_row(r, half)) * BN + wn * 64 + j * 32 + lc] = acc[i][j][r];
+      }
     }
     __syncthreads();
     const int hrow0 = row0 + hh * 128;
@@ -404,41 +465,44 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
     return (int)hipErrorInvalidValue;
   if ((act & 0xff) == 3 && (c_fp32 || bias || resid || !G || (N & 63) || (ldg & 7) || (((uintptr_t)G) & 15)))
     return (int)hipErrorInvalidValue;
-  // 256 x 256 (one workgroup per CU, 4 stages) is the default: equal to the 256 x 128 / two-workgroup form at K = 512 and
-  // 5-10 % ahead at K >= 1408 (profiles/r01_gemm_v3.txt).  CTCLIP_GEMM3_BN=128 selects the latter.
+  // variant: CTCLIP_GEMM3_BN = 256 (one workgroup per CU, 4 stages; default) | 128 (two workgroups per CU, 3 stages);
+  // CTCLIP_GEMM3_M16 = 1 selects the 16x16x32 MFMA form; CTCLIP_GEMM3_STAGGER = start-up delay in 10 ns ticks (BN 128).
   static const int variant = [] {
     const char* e = getenv("CTCLIP_GEMM3_BN");
     return (e && atoi(e) == 128) ? 128 : 256;
   }();
+  static const bool m16 = [] { const char* e = getenv("CTCLIP_GEMM3_M16"); return e && atoi(e) != 0; }();
+  static const int stagger = [] { const char* e = getenv("CTCLIP_GEMM3_STAGGER"); return e ? atoi(e) : 0; }();
+  static const int stagger_shift = [] { const char* e = getenv("CTCLIP_GEMM3_STAGGER_SHIFT"); return e ? atoi(e) : 8; }();
   const int bn = variant;
   Args g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + bn - 1) / bn;
   g.c_fp32 = c_fp32; g.act = act; g.alpha = alpha; g.G = (bf16_t*)G; g.ldg = ldg;
+  g.stagger = (bn == 128) ? stagger * (K / 32) / 16 : 0;   // quoted for K = 512, scaled with the length of the matrix loop
+  g.stagger_shift = stagger_shift; g.stagger_limit = 512;
+#define G3_LAUNCH(BN_, NS_, NT_, M16_, THREADS_, LDS_)                                                                   \
+  do {                                                                                                                    \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<BN_, NS_, NT_, M16_>,                                  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_));                        \
+      if (e != hipSuccess) return (int)e;                                                                                 \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((gemm3_kernel<BN_, NS_, NT_, M16_>), dim3(g.tiles_m * g.tiles_n), dim3(THREADS_), (LDS_), st, g); \
+  } while (0)
   if (bn == 256) {
     const size_t lds = (size_t)4 * (SUB + 256 * BK * 2);   // 128 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<256, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      e = hipFuncSetAttribute((const void*)gemm3_kernel<256, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
-    static const bool nt = getenv("CTCLIP_GEMM3_NO_NT") == nullptr;   // non-temporal epilogue stores: +3..6 % on the K = 512 shapes
-    if (nt) hipLaunchKernelGGL((gemm3_kernel<256, 4, true>), dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
-    else hipLaunchKernelGGL((gemm3_kernel<256, 4, false>), dim3(g.tiles_m * g.tiles_n), dim3(512), lds, st, g);
+    if (m16) G3_LAUNCH(256, 4, true, true, 512, lds);
+    else G3_LAUNCH(256, 4, true, false, 512, lds);
   } else {
     const size_t lds = (size_t)3 * (SUB + 128 * BK * 2);   // 72 KiB: two workgroups per CU
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<128, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm3_kernel<128, 3, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), lds, st, g);
+    if (m16) G3_LAUNCH(128, 3, true, true, 256, lds);
+    else G3_LAUNCH(128, 3, true, false, 256, lds);
   }
+#undef G3_LAUNCH
   return (int)hipGetLastError();
 }
 

@@ -308,6 +308,22 @@ __global__ __launch_bounds__(512) void mfma_probe_kernel(float* __restrict__ out
 }
 }  // namespace
 
+// diagnostic: plain 16-byte-per-lane streaming copy -- the HBM rate this part sustains (read + write bytes), the yardstick
+// next to the 8 TB/s datasheet figure for the HBM-bound kernels (tubelet gather, PEG, LayerNorm, Adam)
+namespace {
+__global__ __launch_bounds__(256) void copy_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n16) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n16; e += (long)gridDim.x * 256) dst[e] = src[e];
+}
+}  // namespace
+
+extern "C" int ctclip_probe_copy(const void* src, void* dst, long bytes, void* stream) {
+  if (bytes <= 0) return 0;
+  if ((bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(copy_probe_kernel, dim3(grid_for(bytes / 16, 16384)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)src, (float4*)dst, bytes / 16);
+  CTCLIP_CHECK_LAUNCH();
+}
+
 extern "C" int ctclip_probe_mfma(float* out, int blocks, int iters, void* stream) {
   hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
   CTCLIP_CHECK_LAUNCH();

@@ -73,7 +73,10 @@ class HipAdam(torch.optim.Optimizer):
                     view = flat_p[o:o + p.numel()].view(p.shape)
                     view.copy_(p.data)
                     p.data = view
-                    p.grad = flat_g[o:o + p.numel()].view(p.shape)
+                    slot = flat_g[o:o + p.numel()].view(p.shape)
+                    if p.grad is not None:                   # a gradient that was there before the arena existed
+                        slot.copy_(p.grad)
+                    p.grad = slot
             self._arenas.append(dict(p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p),
                                      params=ps, offs=offs))
         live = [a for a in self._arenas if a is not None]

@@ -210,6 +210,10 @@ int ctclip_ingest_volume(const void* raw, int raw_is_i16, int H, int W, int D, f
  * what the matrix pipes sustain at the clock the part holds under load (no reference counterpart) ---- */
 int ctclip_probe_mfma(float* out, int blocks, int iters, void* stream);
 
+/* ---- diagnostic: 16-byte-per-lane streaming copy of `bytes` (multiple of 16, 16-byte aligned pointers): the HBM rate the
+ * part sustains, (read + write) bytes / time (no reference counterpart) ---- */
+int ctclip_probe_copy(const void* src, void* dst, long bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,12 +284,32 @@ def test_ctclip_training_steps_golden():
         print(f"  step {s}: loss {loss:.6f} ref {ref:.6f} rel {rel:.2e}; grad-norm {trainer.optim.grad_norm():.4f} "
               f"ref {float(g[f'step{s}.grad_norm']):.4f}")
         assert rel <= 1e-3
-        assert abs(trainer.optim.grad_norm() - float(g[f"step{s}.grad_norm"])) <= 0.1 * float(g[f"step{s}.grad_norm"])
+        assert abs(trainer.optim.grad_norm() - float(g[f"step{s}.grad_norm"])) <= 1e-2 * float(g[f"step{s}.grad_norm"])
         if s == 0:
             # gradients as left in .grad by the step: clipped by min(1, 0.5/norm) like the reference (:199-200)
             coef = min(1.0, 0.5 / (float(g["step0.grad_norm"]) + 1e-6))
             grad_parity(dict(clip.named_parameters()), {k: v * 1.0 for k, v in ref_grads.items()}, 6e-2,
                         "step-0 gradients vs reference")
+    # post-step weights (reference: clip_grad_norm_(0.5) + Adam(lr 1.25e-5), two steps).  Adam's first steps move every
+    # weight by ~lr whatever the gradient's size, so the UPDATE (final - initial) is what is compared: a wrong bias
+    # correction, eps placement, clip coefficient or step count changes its length or direction at once.
+    sd0, final = sub(g, "sd."), clip.state_dict()
+    for k, ref_w in sub(g, "final.").items():
+        if "vq._codebook" in k:
+            continue
+        du, dr = (final[k].detach().cpu() - sd0[k]).double().reshape(-1), (ref_w - sd0[k]).double().reshape(-1)
+        c = float(du @ dr / (du.norm() * dr.norm() + 1e-30))
+        ratio = float(du.norm() / (dr.norm() + 1e-30))
+        print(f"  update of {k}: cosine {c:.5f}, length ratio {ratio:.4f} (|update| {float(dr.norm()):.3e})")
+        assert c >= 0.97 and 0.97 <= ratio <= 1.03, k
+        check("final " + k, final[k], ref_w, 1e-4)
+    # EMA codebook after two training forwards (decay 0.8): free-running codes, so a few rows may differ
+    emb, emb_ref = final["visual_transformer.vq._codebook.embed"].cpu(), g["final.visual_transformer.vq._codebook.embed"]
+    row_ok = ((emb - emb_ref).abs().amax(-1) <= 1e-3).float().mean()
+    print(f"  codebook rows equal to the reference's after two EMA updates: {float(row_ok):.3f}")
+    assert float(row_ok) >= 0.9
+    cs, cs_ref = final["visual_transformer.vq._codebook.cluster_size"].cpu(), g["final.visual_transformer.vq._codebook.cluster_size"]
+    assert float((cs - cs_ref).abs().sum()) <= 0.1 * float(cs_ref.abs().sum()) + 1e-6
 
 
 # ------------------------------------------------------------------------------------------- BASELINE config 1
@@ -373,7 +393,7 @@ def test_config1_two_training_steps():
         print(f"  cfg1 step {s}: hip {loss:.6f} oracle {ref_losses[s]:.6f} rel {rel:.2e}; "
               f"grad-norm {trainer.optim.grad_norm():.4f} / {ref_norms[s]:.4f}")
         assert math.isfinite(loss) and rel <= 5e-2      # free-running codes on a 64-token toy: see test_config1_vs_oracle
-        assert abs(trainer.optim.grad_norm() - ref_norms[s]) <= 0.15 * ref_norms[s]
+        assert abs(trainer.optim.grad_norm() - ref_norms[s]) <= 0.1 * ref_norms[s]       # free-running codes
 
 
 # ------------------------------------------------------------------------------------------- SURVEY 8(f) row f1
