@@ -54,23 +54,110 @@ def synthetic_batch(B, depth, size, L, vocab, device, rank, dtype=torch.bfloat16
     return vol, txt
 
 
-def gemm_traffic(args):
-    """HBM-side bytes per GEMM launch.  bench.py cannot collect PMC counters itself; the figure comes from the committed
-    rocprofv3 passes of this same command (profiles/r01_i_hbm_traffic_b64.csv: separate FETCH_SIZE / WRITE_SIZE runs, read
-    side doubled as MI355X_MICROARCH.md prescribes for gfx950) and is reported only for the configuration they were taken on."""
-    path = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic_b64.csv")
-    if args.small or args.batch != 64 or not os.path.exists(path):
-        return {"traffic": None}
+def pmc_traffic(args):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (separate FETCH_SIZE /
+    WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot collect PMC counters
+    itself; the newest profiles/r*_hbm_traffic_b64.csv is used, and only for the configuration it was taken on.
+    -> (family mean for the GEMM kernels, {kernel-name prefix: bytes per launch})"""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_b64.csv")))
+    if args.small or args.batch != 64 or not paths:
+        return {"traffic": None}, {}
+    path = paths[-1]
     launches = total = 0.0
+    per = {}
     for line in open(path):
         f = line.rsplit(",", 4)
-        if len(f) == 5 and f[0].split("::")[-1].startswith(("gemm3_kernel", "gemm4_kernel", "gemm2_kernel", "gemm_bf16_kernel")):
+        if len(f) != 5 or f[0].startswith(("#", "kernel")):
+            continue
+        name = f[0].split("::")[-1]
+        try:
+            per[name] = float(f[4]) * 1e6
+        except ValueError:
+            continue
+        if name.startswith(("gemm3_kernel", "gemm4_kernel", "gemm2_kernel", "gemm_bf16_kernel")):
             launches += float(f[1])
             total += float(f[1]) * float(f[4]) * 1e6
-    if launches == 0:
-        return {"traffic": None}
-    return {"traffic": total / launches, "traffic_unit": "bytes per launch (mean over the family)",
-            "traffic_source": "profiles/r01_i_hbm_traffic_b64.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+    rel = os.path.relpath(path, ROOT)
+    fam = {"traffic": (total / launches) if launches else None, "traffic_unit": "bytes per launch (mean over the family)",
+           "traffic_source": f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+    return fam, per
+
+
+PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E (guides/MI355X_MICROARCH.md; ~6300 achievable by a float4 copy)
+FF_INNER, FF_INNER_PAD = 1365, 1408    # int(4 * 2/3 * 512) and its zero-padded width: flops are counted UNPADDED
+
+
+def _unpad(n):
+    return {FF_INNER_PAD: FF_INNER, 2 * FF_INNER_PAD: 2 * FF_INNER}.get(n, n)
+
+
+def gemm_work_fns():
+    """work functions for hip.time_kernel: algorithmic flops (2 M N K on the unpadded dims) and algorithmic HBM bytes
+    (operands once + outputs once) of one launch of each entry point of the bf16 MFMA GEMM family."""
+    def plain(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, akm, bkm, c_fp32, *rest):
+        return {"flops": 2.0 * _unpad(M) * _unpad(N) * _unpad(K),
+                "bytes": 2.0 * (M * K + N * K) + M * N * (4.0 if c_fp32 else 2.0) + (4.0 * M * N if resid is not None else 0.0)}
+
+    def geglu(A, B, H, G, M, inner, K, *rest):                 # FF1 + fused GEGLU: h [M, 2 inner] and g [M, inner] written
+        return {"flops": 4.0 * M * _unpad(inner) * K, "bytes": 2.0 * (M * K + 2 * inner * K) + 2.0 * M * 3 * inner}
+
+    def geglu_bwd(dY, W, H, S, M, inner, K, *rest):            # FF2 dgrad + GEGLU backward: h read, d(h) written in place
+        return {"flops": 2.0 * M * _unpad(inner) * K, "bytes": 2.0 * (M * K + inner * K) + 2.0 * M * 4 * inner}
+    return {"gemm_bf16": plain, "gemm_bf16_geglu": geglu, "gemm_bf16_geglu_bwd": geglu_bwd}
+
+
+def other_work_fns():
+    """the kernels north_star names beside the GEMMs: tubelet patch-embed (HBM), spatial attention (MFMA), VQ search."""
+    def patch_fwd(vol, is16, w, b, A, mean, rstd, B, C, Dz, Hy, Wx, tp, p, ldA, *rest):
+        M = B * (Dz // tp) * (Hy // p) * (Wx // p)
+        return {"tag": "patch_embed_fwd", "bytes": float(B * C * Dz * Hy * Wx * (2 if is16 else 4) + M * ldA * 2)}
+
+    def patch_bwd(vol, is16, dA, ldA, mean, rstd, dw, db, B, C, Dz, Hy, Wx, tp, p, *rest):
+        M = B * (Dz // tp) * (Hy // p) * (Wx // p)
+        return {"tag": "patch_embed_bwd", "bytes": float(B * C * Dz * Hy * Wx * (2 if is16 else 4) + M * ldA * 2)}
+
+    def attn_fwd(q, k, v, o, lse, bias, mask, nseq, n, heads, dp, *rest):
+        if n < 256:
+            return None                                         # temporal (n = 24, HBM-bound) and BERT launches: not this entry
+        return {"tag": "spatial_attention_fwd", "flops": 4.0 * nseq * heads * n * n * dp,
+                "bytes": 2.0 * 4 * nseq * n * heads * dp}
+
+    def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, mask, dbias, rel, dtable, tsize, gh, gw, nseq, n, heads, dp, *rest):
+        if n < 256:
+            return None
+        return {"tag": "spatial_attention_bwd", "flops": 10.0 * nseq * heads * n * n * dp,
+                "bytes": 2.0 * 8 * nseq * n * heads * dp}
+
+    def vq(embed, x, pv, pi, ncodes, M, d, *rest):
+        return {"tag": "vq_search", "flops": 2.0 * ncodes * M * d, "bytes": 2.0 * (M * d + ncodes * d) + 8.0 * 16 * M}
+    return {"patch_ln_fwd": patch_fwd, "patch_ln_bwd": patch_bwd, "attn_fwd": attn_fwd, "attn_bwd": attn_bwd, "vq_topk": vq}
+
+
+def measured_peaks(hip, dev):
+    """What this part sustains, next to the datasheet peaks: a register-only MFMA 32x32x16 bf16 loop (no memory traffic) and
+    a float4 streaming copy of 2 GiB."""
+    out = torch.zeros(1, device=dev)
+    blocks, iters = 512, 20000
+    hip.probe_mfma(out, blocks, 200)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); hip.probe_mfma(out, blocks, iters); e1.record()
+    torch.cuda.synchronize()
+    mfma = blocks * 8 * iters * 16 * (2.0 * 32 * 32 * 16) / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    nbytes = 1 << 31
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    hip.probe_copy(src, dst, nbytes)
+    best = 1e30
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); hip.probe_copy(src, dst, nbytes); e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del src, dst
+    return {"mfma_bf16_tflops": mfma, "hbm_copy_gbps": 2.0 * nbytes / (best * 1e-3) / 1e9,
+            "how": "ctclip_probe_mfma (512 x 8 waves x 20000 x 16 MFMA 32x32x16, registers only); ctclip_probe_copy "
+                   "(2 GiB float4 copy, read + write bytes, best of 3)"}
 
 
 def cpu_baseline(model, depth, size, L, vocab, reps=3):
@@ -245,38 +332,52 @@ def main():
     loss = None
     for _ in range(args.warmup):
         loss = trainer.train_step(batch)
-    # dominant kernel: the bf16 MFMA GEMM family.  algorithmic work of a launch = 2*M*N*K.
-    hip.time_kernel("gemm_bf16", lambda A, B, C, bias, resid, M, N, K, *rest: 2.0 * M * N * K)
-    hip.time_kernel("gemm_bf16_geglu", lambda A, B, H, G, M, inner, K, *rest: 4.0 * M * inner * K)      # FF1 + fused GEGLU
-    hip.time_kernel("gemm_bf16_geglu_bwd", lambda dY, W, H, S, M, inner, K, *rest: 2.0 * M * inner * K)  # FF2 dgrad + GEGLU
+    # dominant kernel family: the bf16 MFMA GEMMs.  HIP-event pairs around every launch, on the stream it is launched on,
+    # inside the timed region; algorithmic work of a launch = 2 M N K (unpadded) flops and operand + output bytes.
+    gemm_fns = gemm_work_fns()
+
+    def arm(fns):
+        for name, fn in fns.items():
+            hip.time_kernel(name, fn)
+
+    def family(timed):
+        names = ["ctclip_" + n for n in gemm_fns]
+        items = [it for n in names for it in timed[n]["items"]]
+        ms = sum(m for m, _ in items)
+        flops = sum(w["flops"] for _, w in items)
+        # per-shape bound: a launch can run no faster than max(flops / MFMA peak, bytes / HBM peak)
+        bound = sum(max(w["flops"] / (PEAK_BF16_TFLOPS * 1e12), w["bytes"] / (PEAK_HBM_GBPS * 1e9)) for _, w in items) * 1e3
+        mfma_only = flops / (PEAK_BF16_TFLOPS * 1e12) * 1e3
+        hbm_bound_ms = sum(m for m, w in items if w["bytes"] / (PEAK_HBM_GBPS * 1e9) > w["flops"] / (PEAK_BF16_TFLOPS * 1e12))
+        return {"launches": len(items), "total_ms": ms, "flops": flops, "bytes": sum(w["bytes"] for _, w in items),
+                "bound_ms": bound, "mfma_only_ms": mfma_only, "ms_in_hbm_bound_launches": hbm_bound_ms}
+
+    arm(gemm_fns)
     sync()
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         loss = trainer.train_step(batch)          # returns the python float the reference's train_step returns (.item())
+        step_ms.append(1e3 * (time.perf_counter() - ts))    # .item() is a host sync, so this is the step's wall time
     sync()
     dt = time.perf_counter() - t0
-    def gemm_timing():
-        timed = hip.stop_timing()
-        return {k: sum(timed[n][k] for n in ("ctclip_gemm_bf16", "ctclip_gemm_bf16_geglu", "ctclip_gemm_bf16_geglu_bwd"))
-                for k in ("launches", "total_ms", "work")}
-
-    def arm():
-        hip.time_kernel("gemm_bf16", lambda A, B, C, bias, resid, M, N, K, *rest: 2.0 * M * N * K)
-        hip.time_kernel("gemm_bf16_geglu", lambda A, B, H, G, M, inner, K, *rest: 4.0 * M * inner * K)      # FF1 + fused GEGLU
-        hip.time_kernel("gemm_bf16_geglu_bwd", lambda dY, W, H, S, M, inner, K, *rest: 2.0 * M * inner * K)  # FF2 dgrad + GEGLU
-
-    timing = gemm_timing()
+    timing = family(hip.stop_timing())
     # The weight-gradient GEMMs run on a second stream next to the HBM-bound backward kernels, so inside the timed region
     # a GEMM launch shares the chip and its event-to-event duration is longer than the kernel alone.  Two extra, untimed
-    # steps with that overlap switched off give the family's stand-alone rate as well.
+    # steps with that overlap switched off give the family's stand-alone rate, and time the other kernels north_star names
+    # (tubelet patch-embed, spatial attention, VQ search) undisturbed.
     from ctclip_hip import ops as _ops
     side_was = _ops._side["on"]
     _ops._side["on"] = False
-    arm()
-    for _ in range(2):
+    arm(gemm_fns)
+    arm(other_work_fns())
+    extra = 2
+    for _ in range(extra):
         trainer.train_step(batch)
     sync()
-    alone = gemm_timing()
+    timed2 = hip.stop_timing()
+    alone = family(timed2)
     _ops._side["on"] = side_was
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -285,11 +386,40 @@ def main():
     peak_mem = torch.cuda.max_memory_allocated() / 2 ** 30
 
     if rank == 0:
+        import statistics
         pairs = args.batch * world * args.steps
-        gemm_tflops = timing["work"] / (timing["total_ms"] * 1e-3) / 1e12 if timing["total_ms"] > 0 else 0.0
+        fam_traffic, per_kernel_traffic = pmc_traffic(args)
+        peaks = measured_peaks(hip, dev)
+        gemm_tflops = timing["flops"] / (timing["total_ms"] * 1e-3) / 1e12 if timing["total_ms"] > 0 else 0.0
+        alone_tflops = alone["flops"] / (alone["total_ms"] * 1e-3) / 1e12 if alone["total_ms"] > 0 else 0.0
+        kernels = {}
+        tags = {}
+        for n in ("ctclip_patch_ln_fwd", "ctclip_patch_ln_bwd", "ctclip_attn_fwd", "ctclip_attn_bwd", "ctclip_vq_topk"):
+            for ms, w in timed2.get(n, {}).get("items", []):
+                d = tags.setdefault(w["tag"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+                d["ms"] += ms; d["flops"] += w.get("flops", 0.0); d["bytes"] += w["bytes"]; d["launches"] += 1
+        pmc_names = {"patch_embed_fwd": "patch_ln_fwd_fast", "patch_embed_bwd": "patch_ln_bwd_fast",
+                     "spatial_attention_fwd": "sp_fwd_kernel", "vq_search": "vq_topk3_kernel"}
+        for tag, d in tags.items():
+            if d["ms"] <= 0:
+                continue
+            ent = {"launches_per_step": d["launches"] / extra, "ms_per_step": d["ms"] / extra}
+            if tag.startswith("patch_embed"):
+                gbps = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                ent.update(bound="hbm", achieved=gbps, peak=PEAK_HBM_GBPS, unit="GB/s", frac=gbps / PEAK_HBM_GBPS,
+                           frac_of_measured_copy=gbps / peaks["hbm_copy_gbps"], algorithmic_bytes_per_launch=d["bytes"] / d["launches"])
+            else:
+                tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                ent.update(bound="mfma", achieved=tf, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_BF16_TFLOPS,
+                           frac_of_measured_mfma=tf / peaks["mfma_bf16_tflops"], algorithmic_bytes_per_launch=d["bytes"] / d["launches"])
+            pref = pmc_names.get(tag)
+            hit = [v for k, v in per_kernel_traffic.items() if pref and k.startswith(pref)]
+            ent["traffic"] = hit[0] if hit else None
+            kernels[tag] = ent
         out = {
             "metric": "CT-volume-report pairs/sec (480x480x240 bf16)", "value": pairs / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_median": statistics.median(step_ms), "value_at_median_step": args.batch * world / (statistics.median(step_ms) * 1e-3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("debug-small" if args.small else
                                     "BASELINE configs[1]: CT-ViT base (512d, 4+4 layers, 8x32 heads, cb 8192) + BERT-base-shape "
@@ -297,15 +427,32 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "text_len": args.text_len,
                        "negatives": "local" if args.local_negatives or world == 1 else "global (all-gather)",
                        "parallelism": f"dp{world}", "peak_hbm_gib": round(peak_mem, 1), "final_loss": float(loss)},
-            "roofline": {"kernel": "ctclip_gemm_bf16 family (gemm3_kernel 256x256x32 four-stage LDS-DMA ring for the k-major products, "
-                                   "gemm4_kernel, the same tile with transposed operands, for weight gradients, gemm2/gemm_bf16 kernels for small grids)", "bound": "mfma", "achieved": gemm_tflops,
+            "roofline": {"kernel": "ctclip_gemm_bf16 family (gemm3_kernel for the k-major products incl. the fused GEGLU epilogues, "
+                                   "gemm4_kernel, the same tile with transposed operands, for weight gradients, gemm2/gemm_bf16 kernels for small grids)",
+                         "bound": "mfma", "achieved": gemm_tflops,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_BF16_TFLOPS,
-                         **gemm_traffic(args), "launches_per_step": timing["launches"] / args.steps,
+                         **fam_traffic, "launches_per_step": timing["launches"] / args.steps,
                          "gemm_ms_per_step": timing["total_ms"] / args.steps,
-                         "achieved_without_stream_overlap": alone["work"] / (alone["total_ms"] * 1e-3) / 1e12,
+                         "algorithmic_flops_per_step": timing["flops"] / args.steps,
+                         "algorithmic_bytes_per_launch": timing["bytes"] / max(1, timing["launches"]),
+                         "achieved_without_stream_overlap": alone_tflops,
+                         "frac_without_stream_overlap": alone_tflops / PEAK_BF16_TFLOPS,
+                         "gemm_ms_per_step_without_stream_overlap": alone["total_ms"] / extra,
+                         "per_shape_bound": {
+                             "what": "sum over launches of max(flops / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s): several of the step's "
+                                     "products (out-projection, FF2 with the f32 residual, K = 256/512 data gradients) sit below the "
+                                     "312 FLOP/B ridge and are HBM-bound, so the MFMA-only bound overstates what the family can reach",
+                             "bound_ms_per_step": alone["bound_ms"] / extra, "mfma_only_ms_per_step": alone["mfma_only_ms"] / extra,
+                             "measured_ms_per_step": alone["total_ms"] / extra,
+                             "frac_of_bound": alone["bound_ms"] / alone["total_ms"] if alone["total_ms"] else None,
+                             "share_of_time_in_hbm_bound_launches": alone["ms_in_hbm_bound_launches"] / alone["total_ms"] if alone["total_ms"] else None},
+                         "measured_peaks": peaks,
+                         "frac_of_measured_mfma": gemm_tflops / peaks["mfma_bf16_tflops"],
+                         "frac_of_measured_mfma_without_stream_overlap": alone_tflops / peaks["mfma_bf16_tflops"],
+                         "kernels": kernels,
                          "note": "achieved: HIP-event durations inside the timed region, where weight-gradient GEMMs run "
-                                 "concurrently on a second stream; *_without_stream_overlap: same launches, two extra "
-                                 "untimed steps on one stream"},
+                                 "concurrently on a second stream; *_without_stream_overlap and `kernels`: same launches, two extra "
+                                 "untimed steps on one stream; flops counted on the unpadded GEGLU width 1365"},
         }
         if not args.no_cpu_baseline and world == 1 and not args.small:
             out["cpu_baseline"] = cpu_baseline(model, depth, size, args.text_len, text_cfg["vocab_size"])

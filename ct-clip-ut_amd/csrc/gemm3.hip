@@ -17,6 +17,20 @@
 
 namespace g3 {
 
+#ifdef CTCLIP_G3_STAMPS
+// diagnostic build only (hipcc -DCTCLIP_G3_STAMPS; never compiled into the shipped library): per-workgroup phase stamps
+// {hw id, xcc id, start, first K-step landed, matrix loop done, epilogue done} in 10 ns ticks, read by tools/gemm_timeline.py
+__device__ unsigned long long* g_stamps = nullptr;
+__device__ long g_stamp_cap = 0;
+#define G3_STAMP(slot)                                                                                            \
+  do {                                                                                                            \
+    if (g_stamps && threadIdx.x == 0 && (long)blockIdx.x < g_stamp_cap)                                           \
+      g_stamps[(long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                                 \
+  } while (0)
+#else
+#define G3_STAMP(slot) do { } while (0)
+#endif
+
 constexpr int BM = 256, BK = 32;
 constexpr int SUB = 16384;                 // the A tile of a stage: 256 x 32 bf16 (the B tile follows it)
 
@@ -89,8 +103,20 @@ template <bool NT> __device__ __forceinline__ void st16f(void* p, float a, float
 // M16: the per-wave 128 x 64 tile as 8 x 4 MFMA 16x16x32 instead of 4 x 2 MFMA 32x32x16 -- the same LDS bytes, registers
 //      and matrix-pipe cycles per flop, but the part holds a higher clock on the smaller shape under load
 //      (MI355X_MICROARCH.md, DVFS give-back item 7).
-template <int BN, int NS, bool NTS, bool M16>
+// ROLES (BN = 256, M16): the two waves of a SIMD (w and w + 4, i.e. the wm = 0 and wm = 1 halves of the workgroup) run
+//      half a K-step apart.  In the plain loop all eight waves leave the K-step barrier together, all read their
+//      fragments from LDS together and the matrix pipe idles meanwhile (measured with -DCTCLIP_G3_STAMPS: ~630 of ~1680
+//      cycles per K-step, wave 0 parked at the barrier for 540 of them).  Here every barrier interval has one half in its
+//      MFMA block and the other half in its load block, then they swap:
+//          interval   2k     2k+1    2k+2
+//          wm = 0     R_k    M_k     R_k+1        R = read the fragments of K-step k (12 ds_read_b128), issue this wave's
+//          wm = 1     M_k-1  R_k     M_k              share of the LDS-DMA of K-step k + NS - 1;  M = the 32 MFMAs of K-step k
+//      Stage k is read in intervals 2k (wm 0) and 2k+1 (wm 1), so it is refilled from interval 2k+2 on and must have landed
+//      before interval 2k: each wave waits for its own pieces of stage k+1 (counted vmcnt) inside interval 2k+1.
+//      sq4096 1171 -> 1261 TFLOP/s, ff1 dgrad (K = 2816) 973 -> 1018, the K = 512 shapes +0..2 %.
+template <int BN, int NS, bool NTS, bool M16, bool ROLES = false>
 __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
+  static_assert(!ROLES || (BN == 256 && NS == 4 && M16), "the role-alternating loop is written for the 8-wave 16x16x32 form");
   constexpr int WN = BN / 64, NT = 2 * WN * 64;
   constexpr int STAGE = SUB + BN * BK * 2;
   constexpr int PPW = (STAGE / 1024) / (2 * WN);   // LDS-DMA pieces of 1 KiB per wave and stage: 4 (BN 256) or 6 (BN 128)
@@ -139,6 +165,13 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
+#ifdef CTCLIP_G3_STAMPS
+  if (g_stamps && threadIdx.x == 0 && (long)blockIdx.x < g_stamp_cap) {
+    g_stamps[(long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+    g_stamps[(long)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+  }
+#endif
+  G3_STAMP(2);
   if (g.stagger > 0 && ((blockIdx.x >> g.stagger_shift) & 1) && blockIdx.x < g.stagger_limit) {
     // de-synchronise the two workgroups of a CU (BN = 128): they start together and do identical work, so they stay in
     // lock-step -- both in the matrix loop, then both writing back.  Half a tile period of delay for the second one puts
@@ -151,9 +184,85 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
   for (int t = 0; t < NS - 1; ++t)
     if (t < nk) { issue_part(t, 0); issue_part(t, PPW / 2); }
 
+#ifdef CTCLIP_G3_STAMPS
+  unsigned long long wait_vm = 0, wait_bar = 0;     // shader cycles wave 0 spends in the counted vmcnt wait / at the barrier
+#endif
+  if constexpr (ROLES) {
+    bf16x8 fa[8], fb[4];
+    // own pieces of K-step k+1 landed; up to two younger K-steps (PPW = 4 DMAs each) stay in flight
+#define G3_WAIT_NEXT(k)                                                                \
+    do {                                                                               \
+      if ((k) + 1 < nk) {                                                              \
+        const int y_ = nk - 2 - (k);                                                   \
+        if (y_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  \
+        else if (y_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
+      }                                                                                \
+    } while (0)
+#define G3_BAR()                                                                       \
+    do {                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                               \
+      __builtin_amdgcn_s_barrier();                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+    // the load block also carries this wave's four LDS-DMA pieces of K-step k + NS - 1: issued between the partner's MFMAs
+    // instead (inside the MFMA block) each issue stalls the one wave that is feeding the matrix pipe -- measured slower
+    // (sq4096 1141 vs 1261 TFLOP/s)
+    auto load_block = [&](int k) {
+      const char* sa = smem + (k % NS) * STAGE;
+      const char* sb = sa + SUB;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag16(sb, wn * 64 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = read_frag16(sa, wm * 128 + i * 16, lane);
+      if (k + NS - 1 < nk) { issue_part(k + NS - 1, 0); issue_part(k + NS - 1, PPW / 2); }
+    };
+    auto mfma_block = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc16[i][j] = mfma16(fa[i], fb[j], acc16[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    {                                               // stage 0 has landed for everybody
+      const int y0 = nk - 1;
+      if (y0 >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (y0 == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    G3_BAR();
+    G3_STAMP(3);
+    if (wm == 0) {
+      for (int k = 0; k < nk; ++k) {
+        load_block(k);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        G3_BAR();
+        mfma_block();
+        G3_WAIT_NEXT(k);
+        G3_BAR();
+      }
+      G3_BAR();                                     // the other half's last MFMA block
+    } else {
+      G3_BAR();                                     // interval 0: the other half reads stage 0
+      for (int k = 0; k < nk; ++k) {
+        load_block(k);
+        G3_WAIT_NEXT(k);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        G3_BAR();
+        mfma_block();
+        G3_BAR();
+      }
+    }
+#undef G3_WAIT_NEXT
+#undef G3_BAR
+  } else
   for (int t = 0; t < nk; ++t) {
     // K-step t must have landed; the PPW LDS-DMAs of each of the (up to NS-2) younger steps may stay in flight across the barrier
     const int younger = nk - 1 - t;
+#ifdef CTCLIP_G3_STAMPS
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
     if (NS == 4) {
       if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -162,7 +271,14 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
       if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#ifdef CTCLIP_G3_STAMPS
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();                  // also: every wave is done reading stage (t+3) % NS (K-step t-1)
+#ifdef CTCLIP_G3_STAMPS
+    if (t > 0) { wait_vm += c1 - c0; wait_bar += __builtin_amdgcn_s_memtime() - c1; }
+#endif
+    if (t == 0) G3_STAMP(3);
     const bool pre = t + NS - 1 < nk && !(g.act & 0x200);   // 0x200: timing experiment, no operand traffic after the prologue
     const char* sa = smem + (t % NS) * STAGE;
     const char* sb = sa + SUB;
@@ -197,6 +313,13 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
     }
   }
 
+  G3_STAMP(4);
+#ifdef CTCLIP_G3_STAMPS
+  if (g_stamps && threadIdx.x == 0 && (long)blockIdx.x < g_stamp_cap) {
+    g_stamps[(long)blockIdx.x * 8 + 6] = wait_vm;
+    g_stamps[(long)blockIdx.x * 8 + 7] = wait_bar;
+  }
+#endif
   // epilogue: two 128-row halves through the ring (f32 [128][BN]: 128 / 64 KiB); half h is owned by the waves with wm == h
   const int half = lane >> 5, lc = lane & 31;
   float* ct = (float*)smem;
@@ -320,6 +443,10 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
       }
     }
   }
+#ifdef CTCLIP_G3_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
+#endif
+  G3_STAMP(5);
 }
 
 
@@ -471,9 +598,10 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
     const char* e = getenv("CTCLIP_GEMM3_BN");
     return (e && atoi(e) == 128) ? 128 : 256;
   }();
-  static const bool m16 = [] { const char* e = getenv("CTCLIP_GEMM3_M16"); return e && atoi(e) != 0; }();
+  static const bool m16 = [] { const char* e = getenv("CTCLIP_GEMM3_M16"); return !e || atoi(e) != 0; }();   // default on: +2..6 %
   static const int stagger = [] { const char* e = getenv("CTCLIP_GEMM3_STAGGER"); return e ? atoi(e) : 0; }();
   static const int stagger_shift = [] { const char* e = getenv("CTCLIP_GEMM3_STAGGER_SHIFT"); return e ? atoi(e) : 8; }();
+  static const bool roles = [] { const char* e = getenv("CTCLIP_GEMM3_ROLES"); return !e || atoi(e) != 0; }();
   const int bn = variant;
   Args g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
@@ -482,29 +610,54 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
   g.c_fp32 = c_fp32; g.act = act; g.alpha = alpha; g.G = (bf16_t*)G; g.ldg = ldg;
   g.stagger = (bn == 128) ? stagger * (K / 32) / 16 : 0;   // quoted for K = 512, scaled with the length of the matrix loop
   g.stagger_shift = stagger_shift; g.stagger_limit = 512;
-#define G3_LAUNCH(BN_, NS_, NT_, M16_, THREADS_, LDS_)                                                                   \
+#define G3_LAUNCH(BN_, NS_, NT_, M16_, ROLES_, THREADS_, LDS_)                                                            \
   do {                                                                                                                    \
     static bool attr_set = false;                                                                                         \
     if (!attr_set) {                                                                                                      \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<BN_, NS_, NT_, M16_>,                                  \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<BN_, NS_, NT_, M16_, ROLES_>,                          \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_));                        \
       if (e != hipSuccess) return (int)e;                                                                                 \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
-    hipLaunchKernelGGL((gemm3_kernel<BN_, NS_, NT_, M16_>), dim3(g.tiles_m * g.tiles_n), dim3(THREADS_), (LDS_), st, g); \
+    hipLaunchKernelGGL((gemm3_kernel<BN_, NS_, NT_, M16_, ROLES_>), dim3(g.tiles_m * g.tiles_n), dim3(THREADS_), (LDS_),  \
+                       st, g);                                                                                            \
   } while (0)
   if (bn == 256) {
     const size_t lds = (size_t)4 * (SUB + 256 * BK * 2);   // 128 KiB
-    if (m16) G3_LAUNCH(256, 4, true, true, 512, lds);
-    else G3_LAUNCH(256, 4, true, false, 512, lds);
+    if (m16 && roles) G3_LAUNCH(256, 4, true, true, true, 512, lds);
+    else if (m16) G3_LAUNCH(256, 4, true, true, false, 512, lds);
+    else G3_LAUNCH(256, 4, true, false, false, 512, lds);
   } else {
     const size_t lds = (size_t)3 * (SUB + 128 * BK * 2);   // 72 KiB: two workgroups per CU
-    if (m16) G3_LAUNCH(128, 3, true, true, 256, lds);
-    else G3_LAUNCH(128, 3, true, false, 256, lds);
+    if (m16) G3_LAUNCH(128, 3, true, true, false, 256, lds);
+    else G3_LAUNCH(128, 3, true, false, false, 256, lds);
   }
 #undef G3_LAUNCH
   return (int)hipGetLastError();
 }
+
+#ifdef CTCLIP_G3_STAMPS
+extern "C" int ctclip_debug_gemm3_occupancy(int bn, int m16) {
+  using namespace g3;
+  int n = -1;
+  hipError_t e;
+  if (bn == 128) {
+    const size_t lds = (size_t)3 * (SUB + 128 * BK * 2);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm3_kernel<128, 3, true, true, false>, 256, lds);
+  } else {
+    const size_t lds = (size_t)4 * (SUB + 256 * BK * 2);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm3_kernel<256, 4, true, true, true>, 512, lds);
+  }
+  return e == hipSuccess ? n : -(int)e;
+}
+
+extern "C" int ctclip_debug_gemm3_stamps(void* buf, long capacity_blocks) {
+  unsigned long long* p = (unsigned long long*)buf;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g3::g_stamps), &p, sizeof(p));
+  if (e != hipSuccess) return (int)e;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g3::g_stamp_cap), &capacity_blocks, sizeof(capacity_blocks));
+}
+#endif
 
 // called by ctclip_vq_topk (gemm.hip): codes M % 256 == 0, K % 32 == 0; part_val / part_idx are [N][16]
 int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,

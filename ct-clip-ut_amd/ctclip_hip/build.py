@@ -12,6 +12,11 @@ CSRC = os.path.join(os.path.dirname(PKG), "csrc")
 OBJ = os.path.join(PKG, "_build")
 LIB = os.path.join(PKG, "libctclip_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-fPIC", "-std=c++17", "-Wno-unused-value"]
+# diagnostic builds only (e.g. -DCTCLIP_G3_STAMPS for tools/gemm_timeline.py); objects go to their own directory
+EXTRA = os.environ.get("CTCLIP_EXTRA_HIPCC_FLAGS", "").split()
+if EXTRA:
+    OBJ = os.path.join(PKG, "_build_diag")
+    LIB = os.path.join(PKG, "libctclip_hip_diag.so")
 
 
 def _newer(src, dst, extra=()):
@@ -25,7 +30,7 @@ def _compile(src):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if _newer(src, obj, hdrs):
-        cmd = ["hipcc", *FLAGS, "-c", src, "-o", obj]
+        cmd = ["hipcc", *FLAGS, *EXTRA, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -16,7 +16,8 @@ class HipLibraryMissing(RuntimeError):
 
 
 def library_path():
-    return os.path.join(PKG, "libctclip_hip.so")
+    # CTCLIP_HIP_LIB selects another build of the same ABI (diagnostic builds made with CTCLIP_EXTRA_HIPCC_FLAGS)
+    return os.environ.get("CTCLIP_HIP_LIB") or os.path.join(PKG, "libctclip_hip.so")
 
 
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
@@ -51,18 +52,26 @@ class _Hip:
 
     # -- optional per-launch HIP-event timing (bench.py roofline): events are recorded on the launch stream ----
     def time_kernel(self, name, work_fn):
-        """Record a HIP event pair around every `name` launch; work_fn(*args) -> algorithmic work of that launch."""
+        """Record a HIP event pair around every `name` launch.  work_fn(*args) -> algorithmic work of that launch: a number,
+        or a dict of numbers plus an optional "tag" (launches are then also grouped by tag); None = do not time this one."""
         full = name if name.startswith("ctclip_") else "ctclip_" + name
         self._timed[full] = {"work_fn": work_fn, "events": []}
         self._fns.pop(name, None)
         self._fns.pop(full, None)
 
     def stop_timing(self):
+        """-> {name: {"launches", "total_ms", "work", "items": [(ms, work), ...]}}; `work` is the sum of numeric work (or of
+        each numeric field of dict work)."""
         out = {}
         for k, v in self._timed.items():
             torch.cuda.synchronize()
-            ms = [a.elapsed_time(b) for a, b, _ in v["events"]]
-            out[k] = {"launches": len(ms), "total_ms": float(sum(ms)), "work": float(sum(w for _, _, w in v["events"]))}
+            items = [(a.elapsed_time(b), w) for a, b, w in v["events"]]
+            if items and isinstance(items[0][1], dict):
+                keys = [f for f, x in items[0][1].items() if isinstance(x, (int, float))]
+                work = {f: float(sum(w[f] for _, w in items)) for f in keys}
+            else:
+                work = float(sum(w for _, w in items))
+            out[k] = {"launches": len(items), "total_ms": float(sum(ms for ms, _ in items)), "work": work, "items": items}
         self._timed = {}
         self._fns = {}
         return out
@@ -117,12 +126,13 @@ class _Hip:
                 else:
                     conv.append(a)
             timed = self._timed.get(full)
-            if timed is not None:
+            work = timed["work_fn"](*args) if timed is not None else None
+            if work is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 err = cfn(*conv)
                 e1.record()
-                timed["events"].append((e0, e1, timed["work_fn"](*args)))
+                timed["events"].append((e0, e1, work))
             else:
                 err = cfn(*conv)
             if err != 0:

@@ -2,15 +2,9 @@
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 variants = [
-    ("256x256 m32 (default)", {}),
-    ("256x256 m16", {"CTCLIP_GEMM3_M16": "1"}),
-    ("256x128 2wg", {"CTCLIP_GEMM3_BN": "128"}),
-    ("256x128 2wg stag3us", {"CTCLIP_GEMM3_BN": "128", "CTCLIP_GEMM3_STAGGER": "300"}),
-    ("256x128 2wg stag5us", {"CTCLIP_GEMM3_BN": "128", "CTCLIP_GEMM3_STAGGER": "500"}),
-    ("256x128 2wg stag8us", {"CTCLIP_GEMM3_BN": "128", "CTCLIP_GEMM3_STAGGER": "800"}),
-    ("256x128 2wg stag5us sh3", {"CTCLIP_GEMM3_BN": "128", "CTCLIP_GEMM3_STAGGER": "500", "CTCLIP_GEMM3_STAGGER_SHIFT": "3"}),
-    ("256x128 2wg stag5us sh0", {"CTCLIP_GEMM3_BN": "128", "CTCLIP_GEMM3_STAGGER": "500", "CTCLIP_GEMM3_STAGGER_SHIFT": "0"}),
-    ("256x128 2wg m16 stag5us", {"CTCLIP_GEMM3_BN": "128", "CTCLIP_GEMM3_M16": "1", "CTCLIP_GEMM3_STAGGER": "500"}),
+    ("256x256 m32 lockstep", {"CTCLIP_GEMM3_M16": "0", "CTCLIP_GEMM3_ROLES": "0"}),
+    ("256x256 m16 lockstep", {"CTCLIP_GEMM3_M16": "1", "CTCLIP_GEMM3_ROLES": "0"}),
+    ("256x256 m16 roles", {"CTCLIP_GEMM3_M16": "1", "CTCLIP_GEMM3_ROLES": "1"}),
 ]
 sel = os.environ.get("VARIANTS")
 if sel:
