@@ -225,8 +225,7 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(Args g) {
       for (int r = 0; r < 16; ++r)
         ct[(wm * 64 + i * 32 + acc_row(r, half)) * BN + wn * 64 + j * 32 + lc] = acc[i][j][r];
   __syncthreads();
-  const int act = g.act & 0xff;
-  if (g.act & 0x100) return;
+  const int act = g.act;
   if (g.c_fp32) {
     float* C = (float*)g.C;
     const bool vec = ((g.ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0) &&

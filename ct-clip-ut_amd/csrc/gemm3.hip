@@ -1,16 +1,18 @@
-// bf16 MFMA GEMM, 256 x 256 tile variant for the k-major x k-major products of the CT-CLIP step (every forward and
-// data-gradient projection: C[M,N] = A[M,K] B[N,K]^T with M = all tokens).
+// bf16 MFMA GEMM, 256 x 256 x 32 (or 256 x 128 x 32) tile, for the k-major x k-major products of the CT-CLIP step (every
+// forward and data-gradient projection: C[M,N] = A[M,K] B[N,K]^T with M = all tokens; K = 256 .. 4000, N = 256 .. 2816).
 //
-// gemm2.hip (256 x 128 x 64, 64 x 64 per wave) tops out near 40 % of the MFMA peak: each CU has to pull 48 KiB through
-// L2 -> LDS for every 1024 matrix-pipe cycles and only two stages (96 KiB) can be in flight, so with ~1-2 us of loaded
-// L2/HBM latency the ring runs dry (profiles/r01_gemm_pmc.txt: matrix pipe 28 % busy, LDS 37 %, waves waiting 43 %).
-// This kernel trades tile shape for bytes per flop and depth:
-//   * block tile 256 x 256 x 32, 512 threads = 8 waves (2 x 4), each wave 128 x 64 as 4x2 MFMA 32x32x16
-//     (128 FLOP per operand byte instead of 85; 6 KiB of LDS fragment reads per 8 MFMAs instead of 4 KiB per 4);
-//   * a FOUR-stage ring of 32 KiB stages (128 KiB): three K-steps in flight ahead of the one being consumed;
-//   * global_load_lds (16 B per lane) with the bank swizzle on the SOURCE address, counted `s_waitcnt vmcnt(8)` and one
-//     raw s_barrier per K-step, as in gemm2.hip;
-//   * epilogue through the ring as f32 [128][256] halves -> 16-byte coalesced stores (bias / residual / GELU fused).
+//   * 512 threads = 8 waves, each wave a 128 x 64 (or 64 x 64) slab of MFMA 16x16x32 products (the part holds a higher clock
+//     on this shape than on 32x32x16 at the same cycles per flop: +2..6 % measured);
+//   * a ring of 32 KiB (24 KiB) stages filled by global_load_lds (16 B per lane, bank swizzle on the SOURCE address),
+//     counted `s_waitcnt vmcnt`, raw s_barrier: NS - 1 K-steps in flight ahead of the one being consumed;
+//   * ROLE-ALTERNATING main loop: the two waves of a SIMD run half a K-step apart, one in its MFMA block while the other
+//     reads fragments and issues DMA (see the kernel);
+//   * the MFMAs are issued TRANSPOSED (N-fragment as the A operand) and the N-fragment rows are permuted, so a lane's
+//     accumulators are contiguous output columns of one row: the epilogue converts and stores 16-byte vectors straight from
+//     registers (bias / residual / GELU / both GEGLU forms fused) -- no LDS staging, no barrier.
+// What bounds a short-K tile (measured with -DCTCLIP_G3_STAMPS, tools/gemm_timeline.py): a CU's store path moves ~12 bytes
+// per clock (~24 GB/s; 256 of them are the chip's ~6 TB/s), so writing a 128 KiB bf16 tile takes >= 5.4 us and an f32 one
+// twice that -- 8 workgroups alone on the chip or 19 000 -- next to ~13 us of matrix loop at K = 512.
 // Preconditions (checked by the dispatcher in gemm.hip): both operands k-major, K % 32 == 0, no split-K / accumulate.
 #include "common.h"
 #include <stdlib.h>
@@ -18,38 +20,52 @@
 namespace g3 {
 
 #ifdef CTCLIP_G3_STAMPS
-// diagnostic build only (hipcc -DCTCLIP_G3_STAMPS; never compiled into the shipped library): per-workgroup phase stamps
-// {hw id, xcc id, start, first K-step landed, matrix loop done, epilogue done} in 10 ns ticks, read by tools/gemm_timeline.py
+// diagnostic build only (hipcc -DCTCLIP_G3_STAMPS; never compiled into the shipped library), read by tools/gemm_timeline.py:
+// per-workgroup phase stamps {hw id, xcc id, start, first K-step landed, matrix loop done, stores drained, stores issued} in
+// 10 ns ticks, and per-segment shader-cycle sums of the matrix loop for waves 0 and 4
 __device__ unsigned long long* g_stamps = nullptr;
+__device__ unsigned long long* g_prof = nullptr;   // [blocks][16]
 __device__ long g_stamp_cap = 0;
 #define G3_STAMP(slot)                                                                                            \
   do {                                                                                                            \
     if (g_stamps && threadIdx.x == 0 && (long)blockIdx.x < g_stamp_cap)                                           \
       g_stamps[(long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                                 \
   } while (0)
+#define G3_SEG_DECL() unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long c_ = __builtin_amdgcn_s_memtime()
+#define G3_SEG(n) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg_[n] += t_ - c_; c_ = t_; } while (0)
+#define G3_SEG_STORE()                                                                                            \
+  do {                                                                                                            \
+    if (g_prof && (threadIdx.x == 0 || threadIdx.x == 256) && (long)blockIdx.x < g_stamp_cap)                    \
+      for (int n_ = 0; n_ < 8; ++n_) g_prof[(long)blockIdx.x * 16 + (threadIdx.x >> 8) * 8 + n_] = seg_[n_];     \
+  } while (0)
 #else
 #define G3_STAMP(slot) do { } while (0)
+#define G3_SEG_DECL() do { } while (0)
+#define G3_SEG(n) do { } while (0)
+#define G3_SEG_STORE() do { } while (0)
 #endif
 
 constexpr int BM = 256, BK = 32;
 constexpr int SUB = 16384;                 // the A tile of a stage: 256 x 32 bf16 (the B tile follows it)
 
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 struct Args {
   const bf16_t* A; const bf16_t* B; void* C; const float* bias; const float* resid;
   long lda, ldb, ldc, ldr;
-  int M, N, K, tiles_m, tiles_n, c_fp32, act;
+  int M, N, K, tiles_m, tiles_n, act;
   float alpha;
-  bf16_t* G; long ldg;                             // act == 2: gelu(gate) * value of the 64-column interleaved [val|gate] blocks
-                                                   // act == 3: G = h (pre-activations, same blocks), overwritten with d(h)
-  int stagger, stagger_shift, stagger_limit;       // start-up delay (10 ns ticks) of the workgroups with bit `shift` of blockIdx set
+  bf16_t* G; long ldg;                             // EPI 2: gelu(gate) * value of the 32-column interleaved [val|gate] blocks
+                                                   // EPI 3: G = h (pre-activations, same blocks), overwritten with d(h)
+  int direct;                                      // pointers / strides allow the 16-byte register epilogue
 };
 
-// [256 rows][32 k] bf16 tile, 64-byte rows, 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128 phase
-// (16 consecutive rows, same logical chunk) hit 16 different bank groups
-// Key = (-(r >> 2)) & 3 serves both fragment shapes: a 32x32x16 read (32 consecutive rows, one chunk per lane half) only
-// needs the four row quads of a 16-lane phase on different keys; a 16x16x32 read (16 rows x all four chunks, chunk =
-// lane >> 4) puts row quads {0, 3} with chunk c and {1, 2} with chunk c ^ 1 in one phase, and {k0, k3, 1 ^ k1, 1 ^ k2} =
-// {0, 1, 2, 3} for this key (the plain key r >> 2 collides there).
+// [256 rows][32 k] bf16 tile, 64-byte rows, 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128 phase hit 16
+// different bank groups.  Key = (-(r >> 2)) & 3 serves every fragment shape used on this ring: a 32x32x16 read (32
+// consecutive rows, one chunk per lane half: vq_topk3 below) only needs the four row quads of a 16-lane phase on different
+// keys; a 16x16x32 read (16 rows x all four chunks, chunk = lane >> 4) puts row quads {0, 3} with chunk c and {1, 2} with
+// chunk c ^ 1 in one phase, and {k0, k3, 1 ^ k1, 1 ^ k2} = {0, 1, 2, 3} for this key (the plain key r >> 2 collides); the
+// permuted N-fragment rows of nfrag_row() below land on {0, 2, 3, 1} / {3, 1, 0, 2}.
 __device__ __forceinline__ int swz_key(int r) { return (-(r >> 2)) & 3; }
 __device__ __forceinline__ uint32_t tile_off(int r, int chunk) { return (uint32_t)(r * 64 + ((chunk ^ swz_key(r)) << 4)); }
 
@@ -58,13 +74,19 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int rbase, int s, 
   return *(const bf16x8*)(tile + tile_off(r, 2 * s + (lane >> 5)));
 }
 
-// 16x16x32 operand fragment: lane l holds row rbase + (l & 15), k = 8 (l >> 4) .. + 7 of the 32-deep K-step
-__device__ __forceinline__ bf16x8 read_frag16(const char* tile, int rbase, int lane) {
-  return *(const bf16x8*)(tile + tile_off(rbase + (lane & 15), lane >> 4));
-}
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+
+// A wave's slab is IM (i: 16 rows) x 4 (j) MFMA 16x16x32 products issued as D' = Nfrag_j * Mfrag_i^T, so lane l
+// (q = l >> 4, ml = l & 15) holds D'[4q + r][ml] = C[16 i + ml][slab column of N-fragment row 4q + r], r = 0..3.
+// bf16 outputs: N-fragment j takes the slab's rows   32 (j >> 1) + 8 (a >> 2) + 4 (j & 1) + (a & 3),   a = 0..15,
+// so that lane's 16 values of row 16 i + ml are the slab columns  8q .. 8q+7  (j = 0, 1)  and  32 + 8q .. 32 + 8q+7  (j = 2, 3):
+// two 16-byte bf16 vectors, and in the GEGLU layouts ([val 32 | gate 32] blocks) a value and its gate.
+// f32 outputs use the identity (N-fragment j = slab rows 16 j .. 16 j + 15): the lane's four values of one MFMA are then 4
+// contiguous f32 = one 16-byte store, and the four lanes of a row write 64 contiguous bytes per store instruction (with the
+// permutation an f32 row would be written in 16-byte pieces 32 bytes apart: measured 2x slower).
+__device__ __forceinline__ int nfrag_row(int j, int a) { return 32 * (j >> 1) + 8 * (a >> 2) + 4 * (j & 1) + (a & 3); }
 
 // element offset (from the operand base, at k-tile 0) of the 16 bytes lane `lane` contributes to 1 KiB piece `p`
 // (rows 16p .. 16p+15, 4 chunks each) of the tile whose first row is r0; its LDS destination is piece_base + lane*16
@@ -77,93 +99,101 @@ __device__ __forceinline__ long piece_src(int p, int lane, int r0, int R, long l
 
 __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf_fast(x); }
 
-// streaming 16-byte stores of the epilogue (gigabytes written once, read by a later kernel): non-temporal by default,
-// CTCLIP_GEMM3_NO_NT=1 reverts to plain stores
+// streaming 16-byte stores of the epilogue (gigabytes written once, read by a later kernel): non-temporal, +3..6 % on the
+// K = 512 shapes against plain stores
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-template <bool NT> __device__ __forceinline__ void st16(void* p, uint4 v) {
+__device__ __forceinline__ void st16(void* p, uint4 v) {
   const u32x4_t x = {v.x, v.y, v.z, v.w};
-  if (NT) __builtin_nontemporal_store(x, (u32x4_t*)p);
-  else *(u32x4_t*)p = x;
+  __builtin_nontemporal_store(x, (u32x4_t*)p);
 }
-template <bool NT> __device__ __forceinline__ void st16f(void* p, float a, float b, float c, float d) {
+__device__ __forceinline__ void st16f(void* p, float a, float b, float c, float d) {
   const f32x4_t x = {a, b, c, d};
-  if (NT) __builtin_nontemporal_store(x, (f32x4_t*)p);
-  else *(f32x4_t*)p = x;
+  __builtin_nontemporal_store(x, (f32x4_t*)p);
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+  uint4 o;
+  o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+  return o;
+}
+__device__ __forceinline__ void unpack8(uint4 w, float* v) {
+  const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[2 * e] = __uint_as_float(u[e] << 16); v[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
 }
 
 #define G3_GLDS(gptr, ldsoff)                                                                                     \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                          \
                                    (__attribute__((address_space(3))) void*)(uintptr_t)(ldsoff), 16, 0, 0)
 
-// BN = 256: 8 waves (2 x 4), 4-stage ring of 32 KiB, one workgroup per CU.
-// BN = 128: 4 waves (2 x 2), 3-stage ring of 24 KiB = 72 KiB, TWO workgroups per CU: vmcnt is an in-order counter, so a
-//           wave cannot see its next tile's LDS-DMAs complete before its own epilogue stores have drained to HBM; with two
-//           independent workgroups one computes while the other writes back and refills its ring.
-// M16: the per-wave 128 x 64 tile as 8 x 4 MFMA 16x16x32 instead of 4 x 2 MFMA 32x32x16 -- the same LDS bytes, registers
-//      and matrix-pipe cycles per flop, but the part holds a higher clock on the smaller shape under load
-//      (MI355X_MICROARCH.md, DVFS give-back item 7).
-// ROLES (BN = 256, M16): the two waves of a SIMD (w and w + 4, i.e. the wm = 0 and wm = 1 halves of the workgroup) run
-//      half a K-step apart.  In the plain loop all eight waves leave the K-step barrier together, all read their
-//      fragments from LDS together and the matrix pipe idles meanwhile (measured with -DCTCLIP_G3_STAMPS: ~630 of ~1680
-//      cycles per K-step, wave 0 parked at the barrier for 540 of them).  Here every barrier interval has one half in its
-//      MFMA block and the other half in its load block, then they swap:
-//          interval   2k     2k+1    2k+2
-//          wm = 0     R_k    M_k     R_k+1        R = read the fragments of K-step k (12 ds_read_b128), issue this wave's
-//          wm = 1     M_k-1  R_k     M_k              share of the LDS-DMA of K-step k + NS - 1;  M = the 32 MFMAs of K-step k
-//      Stage k is read in intervals 2k (wm 0) and 2k+1 (wm 1), so it is refilled from interval 2k+2 on and must have landed
-//      before interval 2k: each wave waits for its own pieces of stage k+1 (counted vmcnt) inside interval 2k+1.
-//      sq4096 1171 -> 1261 TFLOP/s, ff1 dgrad (K = 2816) 973 -> 1018, the K = 512 shapes +0..2 %.
-template <int BN, int NS, bool NTS, bool M16, bool ROLES = false>
-__global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
-  static_assert(!ROLES || (BN == 256 && NS == 4 && M16), "the role-alternating loop is written for the 8-wave 16x16x32 form");
-  constexpr int WN = BN / 64, NT = 2 * WN * 64;
-  constexpr int STAGE = SUB + BN * BK * 2;
-  constexpr int PPW = (STAGE / 1024) / (2 * WN);   // LDS-DMA pieces of 1 KiB per wave and stage: 4 (BN 256) or 6 (BN 128)
+// Main loop: the two waves of a SIMD (w and w + 4: role groups 0 and 1) run half a K-step apart.  In a plain loop all eight
+// waves leave the K-step barrier together, all read their fragments from LDS together and the matrix pipe idles meanwhile
+// (measured: ~630 of ~1680 cycles per K-step, wave 0 parked at the barrier for 540 of them).  Here every barrier interval
+// has one group in its MFMA block and the other in its load block, then they swap:
+//     interval   2k     2k+1    2k+2
+//     group 0    R_k    M_k     R_k+1        R = read the fragments of K-step k (ds_read_b128) and issue this wave's share
+//     group 1    M_k-1  R_k     M_k              of the LDS-DMA of K-step k + NS - 1;   M = the MFMAs of K-step k
+// Stage k is read in intervals 2k (group 0) and 2k+1 (group 1), so it is refilled from interval 2k+2 on and must have landed
+// before interval 2k: each wave waits for its own pieces of stage k+1 (counted vmcnt) inside interval 2k+1.
+// Per K-step and wave at 256 x 256 (shader cycles, -DCTCLIP_G3_STAMPS): load block issue ~540 (12 ds_read_b128 + 4 DMA
+// issues of ~85 each), MFMA block ~576, vmcnt wait ~150, barriers ~300: ~1600 against 1024 of matrix-pipe work; the plain
+// loop took ~1680.  Variants measured and dropped: the DMA issues between the MFMAs (they stall the one wave that is
+// feeding the matrix pipe: 1141 vs 1261 TFLOP/s at 4096^3); ONE barrier per K-step with group 0 running [R, M] and group 1
+// [M, R] (the older wave wins the matrix pipe, group 1's MFMA block stretches over both halves: ~1780 cycles per K-step).
+//
+// TWO SHAPES of the same kernel:
+//   TBN = 256: 256 x 256 tile, waves 2 (M) x 4 (N), 128 x 64 per wave (8 x 4 MFMAs), four 32 KiB stages, ONE workgroup per
+//              CU (<= 256 registers).  Least operand traffic per flop.
+//   TBN = 128: 256 x 128 tile, waves 4 (M) x 2 (N), 64 x 64 per wave (4 x 4 MFMAs), three 24 KiB stages, TWO workgroups per
+//              CU (<= 128 registers, 72 KiB of LDS each), so that one computes while the other writes back and refills.
+//              Measured slower on every shape but the f32-output K = 256 one (out-projection: 423 vs 382 TFLOP/s): with
+//              64 x 64 per wave a load block (8 reads + 3 DMA issues) is twice as long as an MFMA block (16 MFMAs) and two
+//              loops running side by side reach ~50 % of the matrix pipe where one 256 x 256 loop reaches ~64 %.
+// EPI selects the epilogue at compile time (one kernel per form keeps the two-workgroup shape inside 128 registers):
+//   0 plain -> bf16   1 plain -> f32   (both: alpha, bias, residual, erf-GELU when g.act == 1)   2 FF1 + GEGLU   3 FF2 dgrad + GEGLU backward
+template <int TBN, int EPI>
+__global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g) {
+  constexpr bool F32OUT = EPI == 1;
+  constexpr int WN = TBN / 64, WM = 8 / WN;            // wave grid: 2 x 4 or 4 x 2
+  constexpr int IM = BM / WM / 16, JN = 4;             // MFMA tiles per wave: 8 x 4 or 4 x 4 (the slab is always 64 columns)
+  constexpr int TNS = (TBN == 256) ? 4 : 3;            // ring stages
+  constexpr int TSTAGE = SUB + TBN * BK * 2;           // 32 / 24 KiB
+  constexpr int TPPW = TSTAGE / 1024 / 8;              // DMA pieces per wave and stage: 4 / 3
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  const int grp = wave >> 2;                           // role group: SIMD partners are waves w and w + 4
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = bid % g.tiles_n;
   const int tm = bid / g.tiles_n;
-  const int row0 = tm * BM, col0 = tn * BN;
+  const int row0 = tm * BM, col0 = tn * TBN;
   const int nk = g.K / BK;
 
-  // piece q = wave * PPW + j of a stage: the first 16 are the A tile, the rest the B tile (stored right behind it)
-  const bf16_t* src[PPW];
-  uint32_t dst[PPW];
+  // piece q = wave * TPPW + j of a stage: the first 16 are the A tile, the rest the B tile (stored right behind it)
+  const bf16_t* src[TPPW];
+  uint32_t dst[TPPW];
 #pragma unroll
-  for (int j = 0; j < PPW; ++j) {
-    const int q = wave * PPW + j;
+  for (int j = 0; j < TPPW; ++j) {
+    const int q = wave * TPPW + j;
     src[j] = (q < 16) ? g.A + piece_src(q, lane, row0, g.M, g.lda) : g.B + piece_src(q - 16, lane, col0, g.N, g.ldb);
     dst[j] = (uint32_t)(q * 1024);
   }
-  auto issue_part = [&](int t, int j0) {           // PPW/2 of this wave's pieces of K-step t -> stage t % NS
-    const uint32_t sb = lds0 + (uint32_t)((t % NS) * STAGE);
+  auto issue_step = [&](int t) {                   // this wave's pieces of K-step t -> stage t % TNS
+    const uint32_t sb = lds0 + (uint32_t)((t % TNS) * TSTAGE);
 #pragma unroll
-    for (int j = j0; j < j0 + PPW / 2; ++j) G3_GLDS(src[j] + (long)t * BK, sb + dst[j]);
+    for (int j = 0; j < TPPW; ++j) G3_GLDS(src[j] + (long)t * BK, sb + dst[j]);
   };
 
-  f32x16 acc[4][2];                                 // 32x32x16 form
-  f32x4 acc16[8][4];                                // 16x16x32 form (only one of the two is live in an instantiation)
-  if (M16) {
+  f32x4 acc[IM][JN];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < IM; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < JN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  }
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
 #ifdef CTCLIP_G3_STAMPS
   if (g_stamps && threadIdx.x == 0 && (long)blockIdx.x < g_stamp_cap) {
@@ -172,279 +202,206 @@ __global__ __launch_bounds__(BN * 2, 2) void gemm3_kernel(Args g) {
   }
 #endif
   G3_STAMP(2);
-  if (g.stagger > 0 && ((blockIdx.x >> g.stagger_shift) & 1) && blockIdx.x < g.stagger_limit) {
-    // de-synchronise the two workgroups of a CU (BN = 128): they start together and do identical work, so they stay in
-    // lock-step -- both in the matrix loop, then both writing back.  Half a tile period of delay for the second one puts
-    // one workgroup's epilogue stores under the other's matrix loop; the pattern then carries itself through the grid.
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(8);
-  }
 
 #pragma unroll
-  for (int t = 0; t < NS - 1; ++t)
-    if (t < nk) { issue_part(t, 0); issue_part(t, PPW / 2); }
+  for (int t = 0; t < TNS - 1; ++t)
+    if (t < nk) issue_step(t);
 
-#ifdef CTCLIP_G3_STAMPS
-  unsigned long long wait_vm = 0, wait_bar = 0;     // shader cycles wave 0 spends in the counted vmcnt wait / at the barrier
-#endif
-  if constexpr (ROLES) {
-    bf16x8 fa[8], fb[4];
-    // own pieces of K-step k+1 landed; up to two younger K-steps (PPW = 4 DMAs each) stay in flight
-#define G3_WAIT_NEXT(k)                                                                \
-    do {                                                                               \
-      if ((k) + 1 < nk) {                                                              \
-        const int y_ = nk - 2 - (k);                                                   \
-        if (y_ >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  \
-        else if (y_ == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
-      }                                                                                \
-    } while (0)
+  // fragment addresses inside a stage: M rows 16 i + ml of this wave's rows, (permuted) N rows of its 64
+  const int ml = lane & 15, q4 = lane >> 4;
+  uint32_t offA, offB[JN];
+  offA = tile_off(wm * (IM * 16) + ml, q4);        // + i * 1024: sixteen rows further, same swizzle key
+#pragma unroll
+  for (int j = 0; j < JN; ++j) offB[j] = SUB + tile_off(wn * 64 + (F32OUT ? 16 * j + ml : nfrag_row(j, ml)), q4);
+
+  bf16x8 fa[IM], fb[JN];
+  // own pieces of K-step k+1 landed; up to TNS - 2 younger K-steps (TPPW DMAs each) stay in flight
+  auto wait_next = [&](int k) {
+    if (k + 1 < nk) {
+      const int y = nk - 2 - k;
+      if (TNS == 4 && y >= 2) wait_vm<2 * TPPW>();
+      else if (y >= 1) wait_vm<TPPW>();
+      else wait_vm<0>();
+    }
+  };
 #define G3_BAR()                                                                       \
-    do {                                                                               \
-      __builtin_amdgcn_sched_barrier(0);                                               \
-      __builtin_amdgcn_s_barrier();                                                    \
-      __builtin_amdgcn_sched_barrier(0);                                               \
-    } while (0)
-    // the load block also carries this wave's four LDS-DMA pieces of K-step k + NS - 1: issued between the partner's MFMAs
-    // instead (inside the MFMA block) each issue stalls the one wave that is feeding the matrix pipe -- measured slower
-    // (sq4096 1141 vs 1261 TFLOP/s)
-    auto load_block = [&](int k) {
-      const char* sa = smem + (k % NS) * STAGE;
-      const char* sb = sa + SUB;
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    __builtin_amdgcn_s_barrier();                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+  auto load_block = [&](int k) {
+    const char* st = smem + (k % TNS) * TSTAGE;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag16(sb, wn * 64 + j * 16, lane);
+    for (int j = 0; j < JN; ++j) fb[j] = *(const bf16x8*)(st + offB[j]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = read_frag16(sa, wm * 128 + i * 16, lane);
-      if (k + NS - 1 < nk) { issue_part(k + NS - 1, 0); issue_part(k + NS - 1, PPW / 2); }
-    };
-    auto mfma_block = [&]() {
-      __builtin_amdgcn_s_setprio(1);
+    for (int i = 0; i < IM; ++i) fa[i] = *(const bf16x8*)(st + offA + i * 1024);
+    if (k + TNS - 1 < nk) issue_step(k + TNS - 1);
+  };
+  auto mfma_block = [&]() {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < IM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc16[i][j] = mfma16(fa[i], fb[j], acc16[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    {                                               // stage 0 has landed for everybody
-      const int y0 = nk - 1;
-      if (y0 >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (y0 == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int j = 0; j < JN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);      // transposed: see nfrag_row()
+    __builtin_amdgcn_s_setprio(0);
+  };
+  {                                                 // stage 0 has landed for everybody
+    const int y0 = nk - 1;
+    if (TNS == 4 && y0 >= 2) wait_vm<2 * TPPW>();
+    else if (y0 >= 1) wait_vm<TPPW>();
+    else wait_vm<0>();
+  }
+  G3_BAR();
+  G3_STAMP(3);
+  G3_SEG_DECL();
+  // profiled segments: 0 load block issue, 1 lgkmcnt wait, 2 barrier after the load block, 3 MFMA block, 4 vmcnt wait,
+  // 5 barrier after the MFMA block
+  if (grp == 0) {
+    for (int k = 0; k < nk; ++k) {
+      load_block(k);
+      G3_SEG(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads retired before the barrier that frees the stage
+      G3_SEG(1);
+      G3_BAR();
+      G3_SEG(2);
+      mfma_block();
+      G3_SEG(3);
+      wait_next(k);
+      G3_SEG(4);
+      G3_BAR();
+      G3_SEG(5);
     }
-    G3_BAR();
-    G3_STAMP(3);
-    if (wm == 0) {
-      for (int k = 0; k < nk; ++k) {
-        load_block(k);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        G3_BAR();
-        mfma_block();
-        G3_WAIT_NEXT(k);
-        G3_BAR();
-      }
-      G3_BAR();                                     // the other half's last MFMA block
-    } else {
-      G3_BAR();                                     // interval 0: the other half reads stage 0
-      for (int k = 0; k < nk; ++k) {
-        load_block(k);
-        G3_WAIT_NEXT(k);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        G3_BAR();
-        mfma_block();
-        G3_BAR();
-      }
+    G3_BAR();                                       // the other group's last MFMA block
+  } else {
+    G3_BAR();                                       // interval 0: the other group reads stage 0
+    G3_SEG(6);
+    for (int k = 0; k < nk; ++k) {
+      load_block(k);
+      G3_SEG(0);
+      wait_next(k);
+      G3_SEG(4);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      G3_SEG(1);
+      G3_BAR();
+      G3_SEG(2);
+      mfma_block();
+      G3_SEG(3);
+      G3_BAR();
+      G3_SEG(5);
     }
-#undef G3_WAIT_NEXT
+  }
+  G3_SEG_STORE();
 #undef G3_BAR
-  } else
-  for (int t = 0; t < nk; ++t) {
-    // K-step t must have landed; the PPW LDS-DMAs of each of the (up to NS-2) younger steps may stay in flight across the barrier
-    const int younger = nk - 1 - t;
-#ifdef CTCLIP_G3_STAMPS
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-#endif
-    if (NS == 4) {
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#ifdef CTCLIP_G3_STAMPS
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
-#endif
-    __builtin_amdgcn_s_barrier();                  // also: every wave is done reading stage (t+3) % NS (K-step t-1)
-#ifdef CTCLIP_G3_STAMPS
-    if (t > 0) { wait_vm += c1 - c0; wait_bar += __builtin_amdgcn_s_memtime() - c1; }
-#endif
-    if (t == 0) G3_STAMP(3);
-    const bool pre = t + NS - 1 < nk && !(g.act & 0x200);   // 0x200: timing experiment, no operand traffic after the prologue
-    const char* sa = smem + (t % NS) * STAGE;
-    const char* sb = sa + SUB;
-    if (M16) {
-      bf16x8 fa[8], fb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag16(sb, wn * 64 + j * 16, lane);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = read_frag16(sa, wm * 128 + i * 16, lane);
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        if (pre) issue_part(t + NS - 1, h2 * (PPW / 2));
-#pragma unroll
-        for (int i = 4 * h2; i < 4 * h2 + 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc16[i][j] = mfma16(fa[i], fb[j], acc16[i][j]);
-      }
-    } else {
-#pragma unroll
-      for (int s = 0; s < BK / 16; ++s) {
-        bf16x8 fa[4], fb[2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = read_frag(sa, wm * 128 + i * 32, s, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = read_frag(sb, wn * 64 + j * 32, s, lane);
-        if (pre) issue_part(t + NS - 1, s * (PPW / 2));   // the next ring slot, half of the pieces between the MFMA groups
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
-      }
-    }
-  }
-
   G3_STAMP(4);
-#ifdef CTCLIP_G3_STAMPS
-  if (g_stamps && threadIdx.x == 0 && (long)blockIdx.x < g_stamp_cap) {
-    g_stamps[(long)blockIdx.x * 8 + 6] = wait_vm;
-    g_stamps[(long)blockIdx.x * 8 + 7] = wait_bar;
-  }
-#endif
-  // epilogue: two 128-row halves through the ring (f32 [128][BN]: 128 / 64 KiB); half h is owned by the waves with wm == h
-  const int half = lane >> 5, lc = lane & 31;
-  float* ct = (float*)smem;
-  const int act = g.act & 0xff;
-#pragma unroll 1
-  for (int hh = 0; hh < 2; ++hh) {
-    __syncthreads();                               // fragment reads of the last stage / the other half's stores are done
-    if (wm == hh) {
-      if (M16) {                                   // acc16[i][j][r] = D[16 i + 4 (lane >> 4) + r][16 j + (lane & 15)]
+
+  const int act = EPI >= 2 ? EPI : g.act;
+  const int colw = col0 + wn * 64;                  // this wave's 64-column slab
+  if (g.direct) {
+    // ---- register epilogue: lane (q4, ml) owns, for each i, row 16 i + ml and (bf16) the slab columns 8 q4 .. +7 and
+    //      32 + 8 q4 .. +7, (f32) 16 j + 4 q4 .. + 3
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < IM; ++i) {
+      __builtin_amdgcn_sched_barrier(0);           // one row group at a time: the two-workgroup shape has 128 registers
+      const int row = row0 + wm * (IM * 16) + i * 16 + ml;
+      if (row >= g.M) continue;
+      if constexpr (F32OUT) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              ct[(i * 16 + 4 * (lane >> 4) + r) * BN + wn * 64 + j * 16 + (lane & 15)] = acc16[i][j][r];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ct[(i * 32 + acc_row(r, half)) * BN + wn * 64 + j * 32 + lc] = acc[i][j][r];
-      }
-    }
-    __syncthreads();
-    const int hrow0 = row0 + hh * 128;
-    if (g.c_fp32) {
-      float* C = (float*)g.C;
-      const bool vec = ((g.ldc & 3) == 0) && ((((uintptr_t)C) & 15) == 0) &&
-                       (!g.resid || (((g.ldr & 3) == 0) && ((((uintptr_t)g.resid) & 15) == 0)));
-#pragma unroll 4
-      for (int it = 0; it < (128 * BN / 4) / NT; ++it) {
-        const int id = it * NT + tid, r = id / (BN / 4), c4 = (id % (BN / 4)) * 4;
-        const int row = hrow0 + r, col = col0 + c4;
-        if (row >= g.M || col >= g.N) continue;
-        const float4 t = *(const float4*)(ct + r * BN + c4);
-        float v[4] = {t.x * g.alpha, t.y * g.alpha, t.z * g.alpha, t.w * g.alpha};
-        if (vec && col + 3 < g.N) {
-          if (g.bias) { const float4 b = *(const float4*)(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-          if (g.resid) { const float4 q = *(const float4*)(g.resid + (long)row * g.ldr + col); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
-          if (act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
-          st16f<NTS>(C + (long)row * g.ldc + col, v[0], v[1], v[2], v[3]);
-        } else {
-          for (int e = 0; e < 4 && col + e < g.N; ++e) {
-            float x = v[e] + (g.bias ? g.bias[col + e] : 0.f);
-            if (g.resid) x += g.resid[(long)row * g.ldr + col + e];
-            if (act == 1) x = gelu_erf(x);
-            C[(long)row * g.ldc + col + e] = x;
-          }
-        }
-      }
-    } else {
-      bf16_t* C = (bf16_t*)g.C;
-      const bool vec = ((g.ldc & 7) == 0) && ((((uintptr_t)C) & 15) == 0) &&
-                       (!g.resid || (((g.ldr & 3) == 0) && ((((uintptr_t)g.resid) & 15) == 0)));
-#pragma unroll 4
-      for (int it = 0; it < (128 * BN / 8) / NT; ++it) {
-        const int id = it * NT + tid, r = id / (BN / 8), c8 = (id % (BN / 8)) * 8;
-        const int row = hrow0 + r, col = col0 + c8;
-        if (row >= g.M || col >= g.N) continue;
-        const float4 t0 = *(const float4*)(ct + r * BN + c8), t1 = *(const float4*)(ct + r * BN + c8 + 4);
-        float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
-        if (act == 3) {
-          // GEGLU backward in the epilogue of dg = dy W2: this tile's dg never goes to memory; the matching value / gate
-          // pre-activations are read from h and replaced by their gradients in place (attention.py:38-41)
-          bf16_t* hv = g.G + (long)row * g.ldg + (long)(col >> 6) * 128 + (col & 63);
-          const uint4 hval = *(const uint4*)hv, hgate = *(const uint4*)(hv + 64);
-          const uint32_t wv[4] = {hval.x, hval.y, hval.z, hval.w}, wg[4] = {hgate.x, hgate.y, hgate.z, hgate.w};
-          float dv[8], dt[8];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v0 = __uint_as_float(wv[e] << 16), v1 = __uint_as_float(wv[e] & 0xffff0000u);
-            const float t0g = __uint_as_float(wg[e] << 16), t1g = __uint_as_float(wg[e] & 0xffff0000u);
-            dv[2 * e] = v[2 * e] * gelu_erf(t0g); dv[2 * e + 1] = v[2 * e + 1] * gelu_erf(t1g);
-            dt[2 * e] = v[2 * e] * v0 * gelu_erf_grad_fast(t0g); dt[2 * e + 1] = v[2 * e + 1] * v1 * gelu_erf_grad_fast(t1g);
-          }
-          uint4 o0, o1;
-          o0.x = pack_bf16x2(dv[0], dv[1]); o0.y = pack_bf16x2(dv[2], dv[3]); o0.z = pack_bf16x2(dv[4], dv[5]); o0.w = pack_bf16x2(dv[6], dv[7]);
-          o1.x = pack_bf16x2(dt[0], dt[1]); o1.y = pack_bf16x2(dt[2], dt[3]); o1.z = pack_bf16x2(dt[4], dt[5]); o1.w = pack_bf16x2(dt[6], dt[7]);
-          st16<NTS>(hv, o0);
-          st16<NTS>(hv + 64, o1);
-          continue;
-        }
-        if (vec && col + 7 < g.N) {
-          if (g.bias) {
-            const float4 b0 = *(const float4*)(g.bias + col), b1 = *(const float4*)(g.bias + col + 4);
-            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-          }
+        for (int j = 0; j < 4; ++j) {
+          const int col = colw + 16 * j + 4 * q4;
+          if (col >= g.N) continue;
+          float x[4] = {acc[i][j][0] * g.alpha, acc[i][j][1] * g.alpha, acc[i][j][2] * g.alpha, acc[i][j][3] * g.alpha};
+          if (g.bias) { const float4 b = *(const float4*)(g.bias + col); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
           if (g.resid) {
-            const float4 q0 = *(const float4*)(g.resid + (long)row * g.ldr + col), q1 = *(const float4*)(g.resid + (long)row * g.ldr + col + 4);
-            v[0] += q0.x; v[1] += q0.y; v[2] += q0.z; v[3] += q0.w; v[4] += q1.x; v[5] += q1.y; v[6] += q1.z; v[7] += q1.w;
+            const float4 r = *(const float4*)(g.resid + (long)row * g.ldr + col);
+            x[0] += r.x; x[1] += r.y; x[2] += r.z; x[3] += r.w;
           }
-          if (act == 1) {
+          if (act == 1) { x[0] = gelu_erf(x[0]); x[1] = gelu_erf(x[1]); x[2] = gelu_erf(x[2]); x[3] = gelu_erf(x[3]); }
+          st16f((float*)g.C + (long)row * g.ldc + col, x[0], x[1], x[2], x[3]);
+        }
+      } else {
+        float v[2][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-          }
-          uint4 o;
-          o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-          st16<NTS>(C + (long)row * g.ldc + col, o);
-          if (act == 2 && ((c8 >> 6) & 1) == 0) {  // a value chunk: its gate sits 64 columns to the right in the same tile
-            const float4 g0 = *(const float4*)(ct + r * BN + c8 + 64), g1 = *(const float4*)(ct + r * BN + c8 + 68);
-            const float gt[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            float w[8];
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = gelu_erf(gt[e] * g.alpha) * v[e];
-            uint4 og;
-            og.x = pack_bf16x2(w[0], w[1]); og.y = pack_bf16x2(w[2], w[3]); og.z = pack_bf16x2(w[4], w[5]); og.w = pack_bf16x2(w[6], w[7]);
-            st16<NTS>(g.G + (long)row * g.ldg + (col >> 7) * 64 + (col & 63), og);
+          for (int e = 0; e < 8; ++e) v[h][e] = acc[i][2 * h + (e >> 2)][e & 3] * g.alpha;
+        if constexpr (EPI == 2) {
+          // FF1 + GEGLU: the slab is one [val 32 | gate 32] block of h; g = gelu(gate) * value (attention.py:38-41)
+          if (colw >= g.N) continue;
+          bf16_t* hp = (bf16_t*)g.C + (long)row * g.ldc + colw + 8 * q4;
+          st16(hp, pack8(v[0]));
+          st16(hp + 32, pack8(v[1]));
+          float w[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = gelu_erf(v[1][e]) * v[0][e];
+          st16(g.G + (long)row * g.ldg + (colw >> 1) + 8 * q4, pack8(w));
+        } else if constexpr (EPI == 3) {
+          // dg = dy W2 with the GEGLU backward: this tile's dg never goes to memory; the matching value / gate
+          // pre-activations are read from h and replaced by their gradients in place
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int c = colw + 32 * h + 8 * q4;   // column of dg; its value sits at (c / 32) * 64 + c % 32 of h, the gate 32 further
+            if (c >= g.N) continue;
+            bf16_t* hv = g.G + (long)row * g.ldg + (long)(c >> 5) * 64 + (c & 31);
+            float val[8], gate[8], dv[8], dt[8];
+            unpack8(*(const uint4*)hv, val);
+            unpack8(*(const uint4*)(hv + 32), gate);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              dv[e] = v[h][e] * gelu_erf(gate[e]);
+              dt[e] = v[h][e] * val[e] * gelu_erf_grad_fast(gate[e]);
+            }
+            st16(hv, pack8(dv));
+            st16(hv + 32, pack8(dt));
           }
         } else {
-          for (int e = 0; e < 8 && col + e < g.N; ++e) {
-            float x = v[e] + (g.bias ? g.bias[col + e] : 0.f);
-            if (g.resid) x += g.resid[(long)row * g.ldr + col + e];
-            if (act == 1) x = gelu_erf(x);
-            C[(long)row * g.ldc + col + e] = f32_to_bf16(x);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int col = colw + 32 * h + 8 * q4;
+            if (col >= g.N) continue;
+            if (g.bias) {
+              const float4 b0 = *(const float4*)(g.bias + col), b1 = *(const float4*)(g.bias + col + 4);
+              v[h][0] += b0.x; v[h][1] += b0.y; v[h][2] += b0.z; v[h][3] += b0.w;
+              v[h][4] += b1.x; v[h][5] += b1.y; v[h][6] += b1.z; v[h][7] += b1.w;
+            }
+            if (g.resid) {
+              const float* rp = g.resid + (long)row * g.ldr + col;
+              const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+              v[h][0] += r0.x; v[h][1] += r0.y; v[h][2] += r0.z; v[h][3] += r0.w;
+              v[h][4] += r1.x; v[h][5] += r1.y; v[h][6] += r1.z; v[h][7] += r1.w;
+            }
+            if (act == 1) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[h][e] = gelu_erf(v[h][e]);
+            }
+            st16((bf16_t*)g.C + (long)row * g.ldc + col, pack8(v[h]));
           }
         }
       }
     }
+  } else {
+    // ---- generic epilogue (unaligned pointers / strides, N % 8 != 0; EPI 0 / 1 only): element-wise from registers
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+      const int row = row0 + wm * (IM * 16) + i * 16 + ml;
+      if (row >= g.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = colw + (F32OUT ? 16 * j + 4 * q4 + r : 32 * (j >> 1) + 8 * q4 + 4 * (j & 1) + r);
+          if (col >= g.N) continue;
+          float x = acc[i][j][r] * g.alpha + (g.bias ? g.bias[col] : 0.f);
+          if (g.resid) x += g.resid[(long)row * g.ldr + col];
+          if (act == 1) x = gelu_erf(x);
+          if (F32OUT) ((float*)g.C)[(long)row * g.ldc + col] = x;
+          else ((bf16_t*)g.C)[(long)row * g.ldc + col] = f32_to_bf16(x);
+        }
+    }
   }
+  G3_STAMP(6);                                        // every store of wave 0 issued
 #ifdef CTCLIP_G3_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and drained
 #endif
   G3_STAMP(5);
 }
@@ -587,68 +544,64 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
                         long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                         hipStream_t st) {
   using namespace g3;
-  if ((act & 0xff) == 2 && (c_fp32 || bias || resid || !G || (N & 127) || (ldc & 7) || (ldg & 7) || (((uintptr_t)C) & 15) ||
-                            (((uintptr_t)G) & 15)))
+  if (act < 0 || act > 3) return (int)hipErrorInvalidValue;
+  if (act == 2 && (c_fp32 || bias || resid || !G || (N & 63) || (ldc & 7) || (ldg & 7) || (((uintptr_t)C) & 15) ||
+                   (((uintptr_t)G) & 15)))
     return (int)hipErrorInvalidValue;
-  if ((act & 0xff) == 3 && (c_fp32 || bias || resid || !G || (N & 63) || (ldg & 7) || (((uintptr_t)G) & 15)))
+  if (act == 3 && (c_fp32 || bias || resid || !G || (N & 31) || (ldg & 7) || (((uintptr_t)G) & 15)))
     return (int)hipErrorInvalidValue;
-  // variant: CTCLIP_GEMM3_BN = 256 (one workgroup per CU, 4 stages; default) | 128 (two workgroups per CU, 3 stages);
-  // CTCLIP_GEMM3_M16 = 1 selects the 16x16x32 MFMA form; CTCLIP_GEMM3_STAGGER = start-up delay in 10 ns ticks (BN 128).
-  static const int variant = [] {
-    const char* e = getenv("CTCLIP_GEMM3_BN");
-    return (e && atoi(e) == 128) ? 128 : 256;
-  }();
-  static const bool m16 = [] { const char* e = getenv("CTCLIP_GEMM3_M16"); return !e || atoi(e) != 0; }();   // default on: +2..6 %
-  static const int stagger = [] { const char* e = getenv("CTCLIP_GEMM3_STAGGER"); return e ? atoi(e) : 0; }();
-  static const int stagger_shift = [] { const char* e = getenv("CTCLIP_GEMM3_STAGGER_SHIFT"); return e ? atoi(e) : 8; }();
-  static const bool roles = [] { const char* e = getenv("CTCLIP_GEMM3_ROLES"); return !e || atoi(e) != 0; }();
-  const int bn = variant;
   Args g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
+  g.act = act; g.alpha = alpha; g.G = (bf16_t*)G; g.ldg = ldg;
+  // the register epilogue moves 16-byte vectors of 8 (bf16) / 4 (f32) columns
+  g.direct = (act >= 2) ||
+             ((N & 7) == 0 && (((uintptr_t)C) & 15) == 0 && (ldc & (c_fp32 ? 3 : 7)) == 0 &&
+              (!bias || (((uintptr_t)bias) & 15) == 0) && (!resid || ((((uintptr_t)resid) & 15) == 0 && (ldr & 3) == 0)));
+  // shape: 256 x 256 (one workgroup per CU) everywhere but the f32-output products with a very short matrix loop (the
+  // out-projection, K = 256: write-back-bound), where two 256 x 128 workgroups per CU overlap one's stores with the other's
+  // loop.  CTCLIP_GEMM3_BN=128|256 forces one shape (experiments).
+  static const int forced = [] { const char* e = getenv("CTCLIP_GEMM3_BN"); return e ? atoi(e) : 0; }();
+  const int bn = (forced == 128 || forced == 256) ? forced : ((c_fp32 && K <= 256) ? 128 : 256);
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + bn - 1) / bn;
-  g.c_fp32 = c_fp32; g.act = act; g.alpha = alpha; g.G = (bf16_t*)G; g.ldg = ldg;
-  g.stagger = (bn == 128) ? stagger * (K / 32) / 16 : 0;   // quoted for K = 512, scaled with the length of the matrix loop
-  g.stagger_shift = stagger_shift; g.stagger_limit = 512;
-#define G3_LAUNCH(BN_, NS_, NT_, M16_, ROLES_, THREADS_, LDS_)                                                            \
+#define G3_LAUNCH(BN_, EPI_, LDS_)                                                                                        \
   do {                                                                                                                    \
     static bool attr_set = false;                                                                                         \
     if (!attr_set) {                                                                                                      \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<BN_, NS_, NT_, M16_, ROLES_>,                          \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_));                        \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<BN_, EPI_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)(LDS_));                                                                    \
       if (e != hipSuccess) return (int)e;                                                                                 \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
-    hipLaunchKernelGGL((gemm3_kernel<BN_, NS_, NT_, M16_, ROLES_>), dim3(g.tiles_m * g.tiles_n), dim3(THREADS_), (LDS_),  \
-                       st, g);                                                                                            \
+    hipLaunchKernelGGL((gemm3_kernel<BN_, EPI_>), dim3(g.tiles_m * g.tiles_n), dim3(512), (LDS_), st, g);                 \
   } while (0)
-  if (bn == 256) {
-    const size_t lds = (size_t)4 * (SUB + 256 * BK * 2);   // 128 KiB
-    if (m16 && roles) G3_LAUNCH(256, 4, true, true, true, 512, lds);
-    else if (m16) G3_LAUNCH(256, 4, true, true, false, 512, lds);
-    else G3_LAUNCH(256, 4, true, false, false, 512, lds);
-  } else {
-    const size_t lds = (size_t)3 * (SUB + 128 * BK * 2);   // 72 KiB: two workgroups per CU
-    if (m16) G3_LAUNCH(128, 3, true, true, false, 256, lds);
-    else G3_LAUNCH(128, 3, true, false, false, 256, lds);
-  }
+#define G3_SHAPES(EPI_)                                                                                                   \
+  do {                                                                                                                    \
+    if (bn == 256) G3_LAUNCH(256, EPI_, (size_t)4 * (SUB + 256 * BK * 2)); /* 128 KiB: one workgroup per CU */           \
+    else G3_LAUNCH(128, EPI_, (size_t)3 * (SUB + 128 * BK * 2));           /* 72 KiB: two workgroups per CU */           \
+  } while (0)
+  const int epi = act >= 2 ? act : (c_fp32 ? 1 : 0);
+  if (epi == 0) G3_SHAPES(0);
+  else if (epi == 1) G3_SHAPES(1);
+  else if (epi == 2) G3_SHAPES(2);
+  else G3_SHAPES(3);
+#undef G3_SHAPES
 #undef G3_LAUNCH
   return (int)hipGetLastError();
 }
 
 #ifdef CTCLIP_G3_STAMPS
-extern "C" int ctclip_debug_gemm3_occupancy(int bn, int m16) {
+extern "C" int ctclip_debug_gemm3_occupancy(int bn, int unused) {
   using namespace g3;
   int n = -1;
-  hipError_t e;
-  if (bn == 128) {
-    const size_t lds = (size_t)3 * (SUB + 128 * BK * 2);
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm3_kernel<128, 3, true, true, false>, 256, lds);
-  } else {
-    const size_t lds = (size_t)4 * (SUB + 256 * BK * 2);
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm3_kernel<256, 4, true, true, true>, 512, lds);
-  }
+  hipError_t e = bn == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm3_kernel<128, 0>, 512, (size_t)3 * (SUB + 128 * BK * 2))
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm3_kernel<256, 0>, 512, (size_t)4 * (SUB + 256 * BK * 2));
   return e == hipSuccess ? n : -(int)e;
+}
+
+extern "C" int ctclip_debug_gemm3_prof(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g3::g_prof), &p, sizeof(p));
 }
 
 extern "C" int ctclip_debug_gemm3_stamps(void* buf, long capacity_blocks) {

@@ -194,6 +194,12 @@ def dgrad(dy16, w16, tokens, n_feat, k_feat, *, out_dtype=F32, resid=None, wT16=
     return gemm(dy16, w16, tokens, k_feat, n_feat, a_kmajor=True, b_kmajor=False, out_dtype=out_dtype, resid=resid)
 
 
+# FF1's weight rows (and h's columns) are stored as [value 32 | gate 32 | value 32 | ...] blocks: a wave's 64-column slab of
+# the 256 x 256 GEMM tile is then one value block and its gate block, and the kernel's register layout (gemm3.hip:nfrag_row)
+# gives every lane a value and its gate, so the GEGLU forward / backward run in the GEMM epilogue without any exchange
+GEGLU_BLOCK = 32
+
+
 def pad64(n: int) -> int:
     return (n + 63) // 64 * 64
 
@@ -567,7 +573,7 @@ class FeedForwardFn(Function):
         # one product over all 2*Ip columns of dh (the pad columns are zero): n2 is streamed once and 2*Ip = 2816 is a
         # whole number of 256-row tiles, where two I = 1365-row products each round up to six
         def ff1_wgrad():
-            gw1p = wgrad(dh, n2, 2 * Ip, dim, M).view(Ip // 64, 2, 64, dim)   # rows in the interleaved [val 64 | gate 64] order
+            gw1p = wgrad(dh, n2, 2 * Ip, dim, M).view(Ip // GEGLU_BLOCK, 2, GEGLU_BLOCK, dim)   # rows in the interleaved [val | gate] block order
             gw1[:I] += gw1p[:, 0].reshape(Ip, dim)[:I]             # value half  (rows 0..I-1 of the reference weight)
             gw1[I:] += gw1p[:, 1].reshape(Ip, dim)[:I]             # gate half   (rows I..2I-1)
         on_side_stream(ff1_wgrad, dh, n2, gw1)

@@ -82,13 +82,15 @@ class FeedForward(nn.Sequential):
 
         def build():
             # value rows 0..I-1 and gate rows I..2I-1 of the reference weight, each zero-padded to Ip and then interleaved
-            # in 64-row blocks [val 64 | gate 64 | val 64 | ...]: a 128/256-column GEMM tile then holds matching value and
-            # gate columns and the GEGLU is applied in the GEMM epilogue (ctclip_gemm_bf16_geglu)
+            # in 32-row blocks [val 32 | gate 32 | val 32 | ...] (ops.GEGLU_BLOCK): each wave's 64-column slab of the GEMM
+            # tile then holds a value block and its gate block and the GEGLU is applied in the GEMM epilogue, straight from
+            # the accumulator registers (ctclip_gemm_bf16_geglu)
             val = torch.zeros(Ip, self.dim, dtype=BF16, device=w1.device)
             gate = torch.zeros(Ip, self.dim, dtype=BF16, device=w1.device)
             val[:I] = w1[:I]
             gate[:I] = w1[I:]
-            w1p = torch.stack((val.view(Ip // 64, 64, self.dim), gate.view(Ip // 64, 64, self.dim)), dim=1).reshape(2 * Ip, self.dim)
+            blk = ops.GEGLU_BLOCK
+            w1p = torch.stack((val.view(Ip // blk, blk, self.dim), gate.view(Ip // blk, blk, self.dim)), dim=1).reshape(2 * Ip, self.dim)
             w1p = w1p.contiguous()
             w2p = torch.zeros(self.dim, Ip, dtype=BF16, device=w2.device)
             w2p[:, :I] = w2

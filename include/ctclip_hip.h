@@ -113,12 +113,12 @@ int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, int block, lo
 int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, int block, long lddg, long ldh,
                      void* stream);
 /* Linear(dim, 2*inner, no bias) + GEGLU in one pass (attention.py:38-50): H[M, 2*inner] = A[M,K] Bw[2*inner,K]^T with the
- * rows of Bw interleaved in 64-row value / gate blocks, and G[M, inner] = gelu(gate) * value written by the same
+ * rows of Bw interleaved in 32-row value / gate blocks, and G[M, inner] = gelu(gate) * value written by the same
  * epilogue (H is still needed by the backward).  inner % 64 == 0, K % 8 == 0. */
 int ctclip_gemm_bf16_geglu(const void* A, const void* Bw, void* H, void* G, int M, int inner, int K, long lda, long ldb,
                            long ldh, long ldg, void* stream);
 /* backward of the same pair: dg = dY[M,K] W2T[inner,K]^T never leaves the chip; the epilogue reads the value / gate
- * pre-activations from H (64-column interleaved blocks) and overwrites them with their gradients (H_dH in place).
+ * pre-activations from H (32-column interleaved blocks) and overwrites them with their gradients (H_dH in place).
  * dG_scratch [M, inner] bf16 is only used by the small-problem path (may be NULL for large ones). */
 int ctclip_gemm_bf16_geglu_bwd(const void* dY, const void* W2T, void* H_dH, void* dG_scratch, int M, int inner, int K,
                                long lddy, long ldw, long ldh, long lddg, void* stream);

@@ -111,27 +111,27 @@ def test_gemm_weight_gradient_kernel(hip, M, N, K, split):
 
 @pytest.mark.parametrize("M,inner,K", [(3000, 384, 96), (2100, 128, 64), (70, 64, 40)])
 def test_linear_geglu_fused_and_blocked_backward(hip, M, inner, K):
-    """ctclip_gemm_bf16_geglu (reference attention.py:38-50): interleaved [val 64 | gate 64] weight rows, H and
+    """ctclip_gemm_bf16_geglu (reference attention.py:38-50): interleaved [val 32 | gate 32] weight rows, H and
     G = gelu(gate) * value from one pass (fused epilogue for the first two shapes, product + blocked GEGLU for the last),
     and the blocked GEGLU backward."""
     x = bf(rnd(M, K, seed=70))
     w = bf(rnd(2 * inner, K, seed=71) * 0.2)                              # reference layout: value rows then gate rows
-    wi = torch.stack((w[:inner].view(inner // 64, 64, K), w[inner:].view(inner // 64, 64, K)), 1).reshape(2 * inner, K).contiguous()
+    wi = torch.stack((w[:inner].view(inner // 32, 32, K), w[inner:].view(inner // 32, 32, K)), 1).reshape(2 * inner, K).contiguous()
     href = x.float() @ w.float().t()
     val, gate = href[:, :inner].clone().requires_grad_(True), href[:, inner:].clone().requires_grad_(True)
     gref = torch.nn.functional.gelu(gate) * val
     H = torch.empty(M, 2 * inner, device=DEV, dtype=torch.bfloat16)
     G = torch.empty(M, inner, device=DEV, dtype=torch.bfloat16)
     hip.gemm_bf16_geglu(x, wi, H, G, M, inner, K, K, K, 2 * inner, inner)
-    Hb = H.float().view(M, inner // 64, 2, 64)
+    Hb = H.float().view(M, inner // 32, 2, 32)
     check("fused h value", Hb[:, :, 0].reshape(M, inner), href[:, :inner], 1e-2)
     check("fused h gate", Hb[:, :, 1].reshape(M, inner), href[:, inner:], 1e-2)
     check("fused g", G, gref, 1.5e-2)
     dg = bf(rnd(M, inner, seed=72))
     gref.backward(dg.float())
     dH = torch.empty_like(H)
-    hip.geglu_bwd(dg, H, dH, M, inner, 64, inner, 2 * inner)
-    dHb = dH.float().view(M, inner // 64, 2, 64)
+    hip.geglu_bwd(dg, H, dH, M, inner, 32, inner, 2 * inner)
+    dHb = dH.float().view(M, inner // 32, 2, 32)
     check("blocked geglu dval", dHb[:, :, 0].reshape(M, inner), val.grad, 2e-2)
     check("blocked geglu dgate", dHb[:, :, 1].reshape(M, inner), gate.grad, 2e-2)
     # dg = dY W2 + GEGLU backward in one pass, in place over H (ctclip_gemm_bf16_geglu_bwd)
@@ -146,7 +146,7 @@ def test_linear_geglu_fused_and_blocked_backward(hip, M, inner, K):
     H2 = H.clone()
     scratch = torch.empty(M, inner, device=DEV, dtype=torch.bfloat16)
     hip.gemm_bf16_geglu_bwd(dY, w2T, H2, scratch, M, inner, Kd, Kd, Kd, 2 * inner, inner)
-    H2b = H2.float().view(M, inner // 64, 2, 64)
+    H2b = H2.float().view(M, inner // 32, 2, 32)
     check("fused dgrad+geglu dval", H2b[:, :, 0].reshape(M, inner), val.grad, 2.5e-2)
     check("fused dgrad+geglu dgate", H2b[:, :, 1].reshape(M, inner), gate.grad, 2.5e-2)
 

@@ -2,9 +2,9 @@
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 variants = [
-    ("256x256 m32 lockstep", {"CTCLIP_GEMM3_M16": "0", "CTCLIP_GEMM3_ROLES": "0"}),
-    ("256x256 m16 lockstep", {"CTCLIP_GEMM3_M16": "1", "CTCLIP_GEMM3_ROLES": "0"}),
-    ("256x256 m16 roles", {"CTCLIP_GEMM3_M16": "1", "CTCLIP_GEMM3_ROLES": "1"}),
+    ("256x256 1wg/CU", {"CTCLIP_GEMM3_BN": "256"}),
+    ("256x128 2wg/CU", {"CTCLIP_GEMM3_BN": "128"}),
+    ("auto", {}),
 ]
 sel = os.environ.get("VARIANTS")
 if sel:

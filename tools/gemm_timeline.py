@@ -27,6 +27,9 @@ for name in os.environ.get("ONLY", "ff1,kv").split(","):
     bn = int(os.environ.get("CTCLIP_GEMM3_BN", 256))
     nblk = ((M + 255) // 256) * ((N + bn - 1) // bn)
     stamps = torch.zeros(nblk, 8, dtype=torch.int64, device="cuda")
+    prof = torch.zeros(nblk, 16, dtype=torch.int64, device="cuda")
+    dll.ctclip_debug_gemm3_prof.argtypes = [ctypes.c_void_p]
+    assert dll.ctclip_debug_gemm3_prof(ctypes.c_void_p(prof.data_ptr())) == 0
     run = lambda: hip.gemm_bf16(A, Bm, C, None, None, M, N, K, K, K, N, 0, 1, 1, cf, 1, 0, 1.0, 0)
     for _ in range(3):
         run()
@@ -48,10 +51,15 @@ for name in os.environ.get("ONLY", "ff1,kv").split(","):
     print(f"   matrix loop                            p10/p50/p90 us: {q(loop_end-landed)}")
     print(f"   epilogue (stores drained)              p10/p50/p90 us: {q(done-loop_end)}")
     print(f"   whole workgroup                        p10/p50/p90 us: {q(done-start)}")
+    pr = prof.cpu().numpy().astype(np.float64)
     nk = K // 32
-    print(f"   wave 0, K-steps 1..{nk-1}: shader cycles in the counted vmcnt wait p50 {np.median(s[:,6])/(nk-1):.0f} per K-step, "
-          f"at the barrier p50 {np.median(s[:,7])/(nk-1):.0f} per K-step (ideal K-step = 1024 matrix-pipe cycles per SIMD)")
-    print(f"   occupancy API: {dll.ctclip_debug_gemm3_occupancy(bn, int(os.environ.get('CTCLIP_GEMM3_M16', 1)))} workgroups per CU")
+    names = ["load issue", "lgkm wait", "barrier(R)", "MFMA block", "vmcnt wait", "barrier(M)"]
+    for w, lab in ((0, "wave 0 (group 0)"), (1, "wave 4 (group 1)")):
+        med = np.median(pr[:, w * 8:w * 8 + 6], axis=0) / nk
+        print(f"   {lab}: shader cycles per K-step: " + ", ".join(f"{n} {v:.0f}" for n, v in zip(names, med)) + f"  = {med.sum():.0f}")
+    issued = (s[:, 6] - s[:, 2].min()) * 0.01
+    print(f"   epilogue: stores of wave 0 issued       p10/p50/p90 us: {q(issued-loop_end)}   (the rest is the drain)")
+    print(f"   occupancy API: {dll.ctclip_debug_gemm3_occupancy(bn, 0)} workgroups per CU")
     # census: the largest number of workgroups simultaneously resident on one CU
     worst = 0
     ev = {}
