@@ -28,15 +28,15 @@ __device__ unsigned long long* g_prof = nullptr;   // [blocks][16]
 __device__ long g_stamp_cap = 0;
 #define G3_STAMP(slot)                                                                                            \
   do {                                                                                                            \
-    if (g_stamps && threadIdx.x == 0 && (long)blockIdx.x < g_stamp_cap)                                           \
-      g_stamps[(long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                                 \
+    if (g_stamps && threadIdx.x == 0 && (long)tile < g_stamp_cap)                                                 \
+      g_stamps[(long)tile * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                                       \
   } while (0)
 #define G3_SEG_DECL() unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long c_ = __builtin_amdgcn_s_memtime()
 #define G3_SEG(n) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg_[n] += t_ - c_; c_ = t_; } while (0)
 #define G3_SEG_STORE()                                                                                            \
   do {                                                                                                            \
-    if (g_prof && (threadIdx.x == 0 || threadIdx.x == 256) && (long)blockIdx.x < g_stamp_cap)                    \
-      for (int n_ = 0; n_ < 8; ++n_) g_prof[(long)blockIdx.x * 16 + (threadIdx.x >> 8) * 8 + n_] = seg_[n_];     \
+    if (g_prof && (threadIdx.x == 0 || threadIdx.x == 256) && (long)tile < g_stamp_cap)                          \
+      for (int n_ = 0; n_ < 8; ++n_) g_prof[(long)tile * 16 + (threadIdx.x >> 8) * 8 + n_] = seg_[n_];           \
   } while (0)
 #else
 #define G3_STAMP(slot) do { } while (0)
@@ -166,46 +166,51 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
   const int grp = wave >> 2;                           // role group: SIMD partners are waves w and w + 4
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid % g.tiles_n;
-  const int tm = bid / g.tiles_n;
-  const int row0 = tm * BM, col0 = tn * TBN;
+  // PERSISTENT over tiles: workgroup b takes the tiles b, b + gridDim.x, ... (gridDim.x = resident workgroups, a multiple
+  // of 8, so a workgroup's tiles keep the XCD-contiguous order of xcd_remap).  When a tile's matrix loop is done the whole
+  // ring is free, so the first NS - 1 K-steps of the NEXT tile are requested before the epilogue's stores are issued: the
+  // ring fill (1.7 us per tile) and the launch gap hide under the ~5 us of write-back.
+  const int total = g.tiles_m * g.tiles_n;
+  int tile = blockIdx.x;
+  if (tile >= total) return;
   const int nk = g.K / BK;
-
+  int row0, col0;
   // piece q = wave * TPPW + j of a stage: the first 16 are the A tile, the rest the B tile (stored right behind it)
   const bf16_t* src[TPPW];
   uint32_t dst[TPPW];
 #pragma unroll
-  for (int j = 0; j < TPPW; ++j) {
-    const int q = wave * TPPW + j;
-    src[j] = (q < 16) ? g.A + piece_src(q, lane, row0, g.M, g.lda) : g.B + piece_src(q - 16, lane, col0, g.N, g.ldb);
-    dst[j] = (uint32_t)(q * 1024);
-  }
+  for (int j = 0; j < TPPW; ++j) dst[j] = (uint32_t)((wave * TPPW + j) * 1024);
+  auto locate = [&](int t) {
+    const int bid = xcd_remap(t, total);
+    row0 = (bid / g.tiles_n) * BM;
+    col0 = (bid % g.tiles_n) * TBN;
+#pragma unroll
+    for (int j = 0; j < TPPW; ++j) {
+      const int q = wave * TPPW + j;
+      src[j] = (q < 16) ? g.A + piece_src(q, lane, row0, g.M, g.lda) : g.B + piece_src(q - 16, lane, col0, g.N, g.ldb);
+    }
+  };
   auto issue_step = [&](int t) {                   // this wave's pieces of K-step t -> stage t % TNS
     const uint32_t sb = lds0 + (uint32_t)((t % TNS) * TSTAGE);
 #pragma unroll
     for (int j = 0; j < TPPW; ++j) G3_GLDS(src[j] + (long)t * BK, sb + dst[j]);
   };
-
-  f32x4 acc[IM][JN];
+  auto issue_prologue = [&]() {
 #pragma unroll
-  for (int i = 0; i < IM; ++i)
-#pragma unroll
-    for (int j = 0; j < JN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    for (int t = 0; t < TNS - 1; ++t)
+      if (t < nk) issue_step(t);
+  };
 
 #ifdef CTCLIP_G3_STAMPS
-  if (g_stamps && threadIdx.x == 0 && (long)blockIdx.x < g_stamp_cap) {
-    g_stamps[(long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
-    g_stamps[(long)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+  if (g_stamps && threadIdx.x == 0 && (long)tile < g_stamp_cap) {
+    g_stamps[(long)tile * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+    g_stamps[(long)tile * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
   }
 #endif
   G3_STAMP(2);
-
-#pragma unroll
-  for (int t = 0; t < TNS - 1; ++t)
-    if (t < nk) issue_step(t);
+  locate(tile);
+  issue_prologue();
+  bool first = true;
 
   // fragment addresses inside a stage: M rows 16 i + ml of this wave's rows, (permuted) N rows of its 64
   const int ml = lane & 15, q4 = lane >> 4;
@@ -215,6 +220,7 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
   for (int j = 0; j < JN; ++j) offB[j] = SUB + tile_off(wn * 64 + (F32OUT ? 16 * j + ml : nfrag_row(j, ml)), q4);
 
   bf16x8 fa[IM], fb[JN];
+  f32x4 acc[IM][JN];
   // own pieces of K-step k+1 landed; up to TNS - 2 younger K-steps (TPPW DMAs each) stay in flight
   auto wait_next = [&](int k) {
     if (k + 1 < nk) {
@@ -246,12 +252,22 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
       for (int j = 0; j < JN; ++j) acc[i][j] = mfma16(fb[j], fa[i], acc[i][j]);      // transposed: see nfrag_row()
     __builtin_amdgcn_s_setprio(0);
   };
-  {                                                 // stage 0 has landed for everybody
+  for (;;) {
+#pragma unroll
+  for (int i = 0; i < IM; ++i)
+#pragma unroll
+    for (int j = 0; j < JN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  if (first) {                                      // stage 0 has landed for everybody
     const int y0 = nk - 1;
     if (TNS == 4 && y0 >= 2) wait_vm<2 * TPPW>();
     else if (y0 >= 1) wait_vm<TPPW>();
     else wait_vm<0>();
+  } else {
+    wait_vm<0>();                                   // the previous tile's stores are younger than this tile's first stages
   }
+  first = false;
   G3_BAR();
   G3_STAMP(3);
   G3_SEG_DECL();
@@ -292,18 +308,24 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
     }
   }
   G3_SEG_STORE();
-#undef G3_BAR
   G3_STAMP(4);
 
+  // every read of the ring was retired before the last barrier: request the next tile's first stages now
+  const int erow0 = row0, ecol0 = col0;
+  const int next = tile + (int)gridDim.x;
+  if (next < total) {
+    locate(next);
+    issue_prologue();
+  }
   const int act = EPI >= 2 ? EPI : g.act;
-  const int colw = col0 + wn * 64;                  // this wave's 64-column slab
+  const int colw = ecol0 + wn * 64;                 // this wave's 64-column slab
   if (g.direct) {
     // ---- register epilogue: lane (q4, ml) owns, for each i, row 16 i + ml and (bf16) the slab columns 8 q4 .. +7 and
     //      32 + 8 q4 .. +7, (f32) 16 j + 4 q4 .. + 3
 #pragma unroll
     for (int i = 0; i < IM; ++i) {
       __builtin_amdgcn_sched_barrier(0);           // one row group at a time: the two-workgroup shape has 128 registers
-      const int row = row0 + wm * (IM * 16) + i * 16 + ml;
+      const int row = erow0 + wm * (IM * 16) + i * 16 + ml;
       if (row >= g.M) continue;
       if constexpr (F32OUT) {
 #pragma unroll
@@ -383,7 +405,7 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
     // ---- generic epilogue (unaligned pointers / strides, N % 8 != 0; EPI 0 / 1 only): element-wise from registers
 #pragma unroll
     for (int i = 0; i < IM; ++i) {
-      const int row = row0 + wm * (IM * 16) + i * 16 + ml;
+      const int row = erow0 + wm * (IM * 16) + i * 16 + ml;
       if (row >= g.M) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -404,6 +426,17 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and drained
 #endif
   G3_STAMP(5);
+  if (next >= total) break;
+  tile = next;
+#ifdef CTCLIP_G3_STAMPS
+  if (g_stamps && threadIdx.x == 0 && (long)tile < g_stamp_cap) {
+    g_stamps[(long)tile * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    g_stamps[(long)tile * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
+  G3_STAMP(2);
+  }
+#undef G3_BAR
 }
 
 
@@ -573,13 +606,21 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
       if (e != hipSuccess) return (int)e;                                                                                 \
       attr_set = true;                                                                                                    \
     }                                                                                                                     \
-    hipLaunchKernelGGL((gemm3_kernel<BN_, EPI_>), dim3(g.tiles_m * g.tiles_n), dim3(512), (LDS_), st, g);                 \
+    hipLaunchKernelGGL((gemm3_kernel<BN_, EPI_>), dim3(grid), dim3(512), (LDS_), st, g);                                  \
   } while (0)
 #define G3_SHAPES(EPI_)                                                                                                   \
   do {                                                                                                                    \
     if (bn == 256) G3_LAUNCH(256, EPI_, (size_t)4 * (SUB + 256 * BK * 2)); /* 128 KiB: one workgroup per CU */           \
     else G3_LAUNCH(128, EPI_, (size_t)3 * (SUB + 128 * BK * 2));           /* 72 KiB: two workgroups per CU */           \
   } while (0)
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? (n / 8) * 8 : 256;                 // a multiple of 8 keeps a workgroup's tiles on one XCD's run
+  }();
+  const long total = (long)g.tiles_m * g.tiles_n;
+  const long resident = (long)cus * (bn == 256 ? 1 : 2);
+  const int grid = (int)(total < resident ? total : resident);
   const int epi = act >= 2 ? act : (c_fp32 ? 1 : 0);
   if (epi == 0) G3_SHAPES(0);
   else if (epi == 1) G3_SHAPES(1);
