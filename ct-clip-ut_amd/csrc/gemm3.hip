@@ -210,7 +210,8 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
   G3_STAMP(2);
   locate(tile);
   issue_prologue();
-  bool first = true;
+  bool first = true, counted = false;
+  constexpr int NST = IM * (EPI == 0 ? 2 : EPI == 2 ? 3 : 4);   // 16-byte stores per wave of a full tile's register epilogue
 
   // fragment addresses inside a stage: M rows 16 i + ml of this wave's rows, (permuted) N rows of its 64
   const int ml = lane & 15, q4 = lane >> 4;
@@ -264,8 +265,13 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
     if (TNS == 4 && y0 >= 2) wait_vm<2 * TPPW>();
     else if (y0 >= 1) wait_vm<TPPW>();
     else wait_vm<0>();
+  } else if (counted) {
+    // the previous tile's NST epilogue stores are younger than this tile's first stages (vmcnt retires in order): leave
+    // them and K-steps 1, 2 in flight.  The in-loop waits of K-steps 0 and 1 then over-wait (they count as if only DMAs
+    // were outstanding), which gives the stores two K-steps to drain under the matrix loop instead of blocking here.
+    wait_vm<NST + (TNS - 2) * TPPW>();
   } else {
-    wait_vm<0>();                                   // the previous tile's stores are younger than this tile's first stages
+    wait_vm<0>();                                   // ragged previous tile: its store count is not a constant
   }
   first = false;
   G3_BAR();
@@ -317,6 +323,7 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
     locate(next);
     issue_prologue();
   }
+  counted = g.direct && erow0 + BM <= g.M && ecol0 + TBN <= g.N && nk >= TNS - 1;
   const int act = EPI >= 2 ? EPI : g.act;
   const int colw = ecol0 + wn * 64;                 // this wave's 64-column slab
   if (g.direct) {
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
         }
       }
     }
-  } else {
+  } else if constexpr (EPI < 2) {
     // ---- generic epilogue (unaligned pointers / strides, N % 8 != 0; EPI 0 / 1 only): element-wise from registers
 #pragma unroll
     for (int i = 0; i < IM; ++i) {
@@ -620,7 +627,8 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
   }();
   const long total = (long)g.tiles_m * g.tiles_n;
   const long resident = (long)cus * (bn == 256 ? 1 : 2);
-  const int grid = (int)(total < resident ? total : resident);
+  static const bool persist = [] { const char* e = getenv("CTCLIP_GEMM3_PERSIST"); return !e || atoi(e) != 0; }();   // 0: one tile per workgroup (A/B)
+  const int grid = (int)((total < resident || !persist) ? total : resident);
   const int epi = act >= 2 ? act : (c_fp32 ? 1 : 0);
   if (epi == 0) G3_SHAPES(0);
   else if (epi == 1) G3_SHAPES(1);

@@ -2,9 +2,10 @@
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 variants = [
-    ("256x256 1wg/CU", {"CTCLIP_GEMM3_BN": "256"}),
-    ("256x128 2wg/CU", {"CTCLIP_GEMM3_BN": "128"}),
-    ("auto", {}),
+    ("one tile per wg", {"CTCLIP_GEMM3_PERSIST": "0"}),
+    ("persistent", {"CTCLIP_GEMM3_PERSIST": "1"}),
+    ("one tile per wg (2)", {"CTCLIP_GEMM3_PERSIST": "0"}),
+    ("persistent (2)", {"CTCLIP_GEMM3_PERSIST": "1"}),
 ]
 sel = os.environ.get("VARIANTS")
 if sel:
