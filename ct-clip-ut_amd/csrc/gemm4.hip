@@ -9,11 +9,12 @@
 //   * a stage holds A[32 k][256 m] and B[32 k][256 n] (512-byte k-rows, 32 KiB), ring of four stages; global_load_lds
 //     moves two whole k-rows per wave-instruction, the bank swizzle applied to the SOURCE column chunk;
 //   * fragments come out of LDS with ds_read_b64_tr_b16 (the MFMA wants 8 consecutive k per lane, memory has 8
-//     consecutive m): twelve transposed reads per 16-wide k-step and wave, issued as inline asm (see gemm2.hip) and
-//     double-buffered -- the reads of k-step s+1 are in flight under the MFMAs of k-step s;
+//     consecutive m): twelve transposed reads per 16-wide k-step and wave, issued as inline asm (see gemm2.hip);
+//   * role-alternating main loop (the two waves of a SIMD half a K-step apart), as in gemm3.hip;
 //   * epilogue: f32 atomics straight from the accumulators (each register covers two 128-byte row segments).
 // Preconditions (checked by the dispatcher in gemm.hip): both operands m/n-major, K % 32 == 0, f32 accumulate output.
 #include "common.h"
+#include <stdlib.h>
 
 namespace g4 {
 
@@ -138,26 +139,71 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
       for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);
   };
 
-  for (int t = 0; t < nk; ++t) {
-    // K-step t must have landed; the PPW LDS-DMAs of each of the (up to NS-2) younger steps may stay in flight across the barrier
-    const int younger = nk - 1 - t;
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                  // also: every wave is done reading stage (t+3) % NS (K-step t-1)
-    const bool pre = t + NS - 1 < nk;
-    const uint32_t sa_l = lds0 + (uint32_t)((t % NS) * STAGE);
-    short4v r0[12], r1[12];
+  // Role-alternating loop, as in gemm3.hip: the two waves of a SIMD (w and w + 4, i.e. wm = 0 / 1) run half a K-step apart,
+  // one in its MFMA block (16 MFMA 32x32x16) while the other reads its 24 transposed fragments and issues its four LDS-DMA
+  // pieces of K-step k + NS - 1; stage k is read in intervals 2k (wm 0) and 2k+1 (wm 1), refilled from interval 2k+2 on,
+  // and each wave waits for its own pieces of stage k+1 (counted vmcnt) inside interval 2k+1.  Against the lock-step loop
+  // (one barrier per K-step, fragment reads of the second half under the MFMAs of the first): ff1 wgrad 912 -> 1039
+  // TFLOP/s, ff2 847 -> 980, kv 842 -> 958, patch 927 -> 1090 (same box, interleaved).
+  short4v r0[12], r1[12];
+  auto wait_next = [&](int k) {
+    if (k + 1 < nk) {
+      const int y = nk - 2 - k;
+      if (y >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (y == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+#define G4_BAR()                                                                       \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    __builtin_amdgcn_s_barrier();                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+  auto load_block = [&](int k) {
+    const uint32_t sa_l = lds0 + (uint32_t)((k % NS) * STAGE);
     read_set(r0, sa_l, 0);
-    if (pre) issue_part(t + NS - 1, 0);
-    tr_wait(r0);
-    read_set(r1, sa_l, 1);                         // in flight under the MFMAs of the first half
-    if (pre) issue_part(t + NS - 1, PPW / 2);
+    read_set(r1, sa_l, 1);
+    if (k + NS - 1 < nk) { issue_part(k + NS - 1, 0); issue_part(k + NS - 1, PPW / 2); }
+  };
+  auto mfma_block = [&]() {
+    __builtin_amdgcn_s_setprio(1);
     mma_set(r0);
-    __builtin_amdgcn_sched_barrier(0);             // keep the first half's MFMAs in front of the wait
-    tr_wait(r1);
     mma_set(r1);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  {                                                 // stage 0 has landed for everybody
+    const int y0 = nk - 1;
+    if (y0 >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (y0 == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  G4_BAR();
+  if (wm == 0) {
+    for (int k = 0; k < nk; ++k) {
+      load_block(k);
+      tr_wait(r0);
+      tr_wait(r1);
+      G4_BAR();
+      mfma_block();
+      wait_next(k);
+      G4_BAR();
+    }
+    G4_BAR();                                       // the other half's last MFMA block
+  } else {
+    G4_BAR();                                       // interval 0: the other half reads stage 0
+    for (int k = 0; k < nk; ++k) {
+      load_block(k);
+      wait_next(k);
+      tr_wait(r0);
+      tr_wait(r1);
+      G4_BAR();
+      mfma_block();
+      G4_BAR();
+    }
+  }
+#undef G4_BAR
+
 
   // split-K: f32 atomics straight from the accumulators.  For a fixed register the 64 lanes cover two 128-byte row
   // segments -- the access shape global_atomic_add_f32 runs at full rate with.

@@ -2,10 +2,10 @@
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 variants = [
-    ("one tile per wg", {"CTCLIP_GEMM3_PERSIST": "0"}),
-    ("persistent", {"CTCLIP_GEMM3_PERSIST": "1"}),
-    ("one tile per wg (2)", {"CTCLIP_GEMM3_PERSIST": "0"}),
-    ("persistent (2)", {"CTCLIP_GEMM3_PERSIST": "1"}),
+    ("gemm4 lockstep", {"CTCLIP_GEMM4_ROLES": "0"}),
+    ("gemm4 roles", {"CTCLIP_GEMM4_ROLES": "1"}),
+    ("gemm4 lockstep (2)", {"CTCLIP_GEMM4_ROLES": "0"}),
+    ("gemm4 roles (2)", {"CTCLIP_GEMM4_ROLES": "1"}),
 ]
 sel = os.environ.get("VARIANTS")
 if sel:
