@@ -615,7 +615,7 @@ inline int waves_for(int n, int dhead, int cap32 = 9) {
 // heads per workgroup for short sequences (all row tiles of a head fit one group of `nw` waves): the largest divisor of
 // `heads` whose waves fit the kernel's launch bound and whose LDS regions stay under the default 64 KiB
 inline int heads_per_block(int n_pad, int nw, int heads, int max_waves, size_t lds_per_head) {
-  static const bool off = getenv("CTCLIP_ATTN_HPB1") != nullptr;
+  static const bool off = CTCLIP_KNOB("CTCLIP_ATTN_HPB1") != nullptr;
   if (off || n_pad / 32 > nw) return 1;
   for (int d = heads; d >= 1; --d)
     if (heads % d == 0 && d * nw <= max_waves && d * lds_per_head <= 65536) return d;
@@ -686,7 +686,7 @@ int ctclip_attn_bwd_dropout(const void* q, const void* k, const void* v, const v
     const int e = ctclip_attn_sp_bwd(a, dhead, (hipStream_t)stream);
     if (e >= 0) return e;
   }
-  static const bool no_small = getenv("CTCLIP_ATTN_NO_SMALL") != nullptr;
+  static const bool no_small = CTCLIP_KNOB("CTCLIP_ATTN_NO_SMALL") != nullptr;
   if (dhead == 32 && n <= 32 && !a.dbias_dense && !a.dbias_table && !a.drop && !no_small) {
     const long items = (long)nseq * heads;
     const int wpb = 8;

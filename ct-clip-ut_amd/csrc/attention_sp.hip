@@ -27,6 +27,13 @@ constexpr float kLn2 = 0.6931471805599453f;
 constexpr int kMaxWaves = 8;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;  // one 16-byte piece of an image row
 
+// timing ablations (drop a barrier / the combine / the next-sequence fetch): compiled in for tuning builds only
+#ifdef CTCLIP_TUNING_KNOBS
+#define SP_DBG(bit) (p.dbg & (bit))
+#else
+#define SP_DBG(bit) false
+#endif
+
 struct SpArgs {
   AttnArgs a;
   int T;        // 32-wide tiles per row (n / 32)
@@ -36,7 +43,7 @@ struct SpArgs {
   int chunk;    // sequences per workgroup
   float c1;     // scale * log2(e)
   float inv_scale;
-  int dbg;      // timing experiments only (CTCLIP_ATTN_SP_DBG): 1 = every iteration re-loads the first sequence
+  int dbg;      // timing ablations, -DCTCLIP_TUNING_KNOBS builds only (always 0 in the product library)
 };
 
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(512) void sp_fwd_kernel(SpArgs p) {
 
   for (int seq = seq0; seq < seq1; ++seq) {
     const int buf = (seq - seq0) & 1;
-    const long sn = (p.dbg & 1) ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);   // next sequence (the last re-loads its own)
+    const long sn = SP_DBG(1) ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);   // next sequence (the last re-loads its own)
     const bf16x8 qf0 = row_frag<32>(qbuf + buf * 2048, 0, 0, lane), qf1 = row_frag<32>(qbuf + buf * 2048, 0, 1, lane);
     f32x16 S[TPW];
 #pragma unroll
@@ -239,11 +246,11 @@ __global__ __launch_bounds__(512) void sp_fwd_kernel(SpArgs p) {
     // is then in flight across the loop edge, where the only vmcnt wait it could place would also cover the combine's stores
 #pragma unroll
     for (int u = 0; u < TPW; ++u) asm volatile("" : "+v"(kf[u][0]), "+v"(kf[u][1]));
-    if (!(p.dbg & 4)) lds_barrier();
+    if (!SP_DBG(4)) lds_barrier();
     // combine the W partial rows: O = sum_w 2^(m_w - m) O_w / sum_w 2^(m_w - m) l_w.  Done by the LAST four waves: when
     // the tiles do not divide evenly the first waves carry the extra tile.
     const int idx = (p.W == 8) ? (((w & 2) ? (((w >> 2) << 1) | (w & 1)) : -1) * 64 + lane) : tid - (nthreads - 256);
-    if (idx >= 0 && !(p.dbg & 8)) {
+    if (idx >= 0 && !SP_DBG(8)) {
       const int cl = idx & 63, rg = idx >> 6, q = cl & 31, ch = cl >> 5;
       float mw[kMaxWaves], lw[kMaxWaves];
       float4 tw[kMaxWaves];
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(512) void sp_bwd_dq_kernel(SpArgs p) {
 
   for (int seq = seq0; seq < seq1; ++seq) {
     const int buf = (seq - seq0) & 1;
-    const long sn = (p.dbg & 1) ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);
+    const long sn = SP_DBG(1) ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);
     const char* qdb = qd + buf * 4096;
     const bf16x8 qf0 = row_frag<32>(qdb, 0, 0, lane), qf1 = row_frag<32>(qdb, 0, 1, lane);
     const bf16x8 df0 = row_frag<32>(qdb + 2048, 0, 0, lane), df1 = row_frag<32>(qdb + 2048, 0, 1, lane);
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(512) void sp_bwd_dkv_kernel(SpArgs p) {
 
   for (int seq = seq0; seq < seq1; ++seq) {
     const int buf = (seq - seq0) & 1;
-    const long sn = (p.dbg & 1) ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);
+    const long sn = SP_DBG(1) ? seq0 : (seq + 1 < seq1 ? seq + 1 : seq);
     const char* kvb = kvbuf + buf * 4096;
     const bf16x8 kf0 = row_frag<32>(kvb, 0, 0, lane), kf1 = row_frag<32>(kvb, 0, 1, lane);
     const bf16x8 vf0 = row_frag<32>(kvb + 2048, 0, 0, lane), vf1 = row_frag<32>(kvb + 2048, 0, 1, lane);
@@ -594,12 +601,12 @@ __global__ __launch_bounds__(512) void sp_bwd_dkv_kernel(SpArgs p) {
         dkacc = mfma32(tr_frag<32>(qimg, qrow0, 1, 0, lane), d1, dkacc);
         __builtin_amdgcn_sched_barrier(0);
       }
-    if (!(p.dbg & 16)) lds_barrier();                    // the previous sequence's combine has left partk / partv
+    if (!SP_DBG(16)) lds_barrier();                    // the previous sequence's combine has left partk / partv
     part_store(partk, w, lane, dkacc);
     part_store(partv, w, lane, dvacc);
     st_staged(buf ^ 1);                                  // own Q / dO rows + stats (own reads are done), next K / V block
-    if (!(p.dbg & 4)) lds_barrier();
-    if (!(p.dbg & 8))
+    if (!SP_DBG(4)) lds_barrier();
+    if (!SP_DBG(8))
     for (int idx = tid; idx < 512; idx += nthreads) {
       const int which = idx >> 8, cl = idx & 63, rg = (idx >> 6) & 3, key = cl & 31, ch = cl >> 5;
       const float4 acc = part_sum(which ? partv : partk, p.W, cl, rg);
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(512) void sp_bwd_dkv_kernel(SpArgs p) {
 // ------------------------------------------------------------------------------------------------
 bool sp_enabled() {
   static const bool on = [] {
-    const char* e = getenv("CTCLIP_ATTN_SP");
+    const char* e = CTCLIP_KNOB("CTCLIP_ATTN_SP");
     return !(e && e[0] == '0');
   }();
   return on;
@@ -657,7 +664,7 @@ SpArgs sp_plan(const AttnArgs& a, int* nblocks) {
   // faster forward and 2 % faster backward than 220 (4 rounds) -- the tail of a 4-round launch costs more than the extra
   // bias loads / d(bias) flushes
   if (p.chunk > 32) p.chunk = 32;
-  if (const char* e = getenv("CTCLIP_ATTN_SP_DBG")) p.dbg = atoi(e);
+  if (const char* e = CTCLIP_KNOB("CTCLIP_ATTN_SP_DBG")) p.dbg = atoi(e);
   if (const char* e = getenv("CTCLIP_ATTN_SP_CHUNK")) {  // test knob: force the number of sequences per workgroup
     const int forced = atoi(e);
     if (forced > 0) p.chunk = forced < a.nseq ? forced : a.nseq;

@@ -6,6 +6,19 @@
 
 typedef uint16_t bf16_t;  // raw bfloat16 storage
 
+// Environment inputs.  The shipped library reads exactly two variables, both TEST HOOKS documented in include/ctclip_hip.h:
+//   CTCLIP_GEMM_V2_ALL    lower the size gates of the pipelined GEMM kernels, so the test-suite reaches every kernel with
+//                         small shapes;
+//   CTCLIP_ATTN_SP_CHUNK  sequences per workgroup of the sequence-persistent attention kernels (ragged-chunk tests).
+// A/B switches and timing ablations of the development rounds exist only in builds made with -DCTCLIP_TUNING_KNOBS
+// (CTCLIP_EXTRA_HIPCC_FLAGS of ctclip_hip/build.py, which writes libctclip_hip_diag.so next to the product library).
+#include <stdlib.h>
+#ifdef CTCLIP_TUNING_KNOBS
+#define CTCLIP_KNOB(name) getenv(name)
+#else
+#define CTCLIP_KNOB(name) ((const char*)nullptr)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short short4v;
 typedef __attribute__((ext_vector_type(8))) short short8v;

@@ -450,10 +450,10 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
     // register-staged 128x128 kernel below.  CTCLIP_GEMM_V2_ALL=1 lowers the size gate (the tests do, to cover every
     // path with small shapes); CTCLIP_GEMM_V1=1 disables the pipelined kernel.
     static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
-    static const bool force_v1 = getenv("CTCLIP_GEMM_V1") != nullptr;
+    static const bool force_v1 = CTCLIP_KNOB("CTCLIP_GEMM_V1") != nullptr;
     // k-major x k-major products with many 256 x 256 tiles (every forward / data-gradient projection over all tokens) go
     // to the deeper, more compute-dense gemm3.hip.  CTCLIP_GEMM_NO_V3=1 disables it.
-    static const bool no_v3 = getenv("CTCLIP_GEMM_NO_V3") != nullptr;
+    static const bool no_v3 = CTCLIP_KNOB("CTCLIP_GEMM_NO_V3") != nullptr;
     const long blocks3 = (long)((M + 255) / 256) * ((N + 255) / 256);
     if (!no_v3 && !force_v1 && a_kmajor && b_kmajor && (K % 32) == 0 && split_k <= 1 && !accumulate &&
         (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
@@ -461,7 +461,7 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
                                  (hipStream_t)stream);
     // weight gradients (m-major x n-major, split over the tokens, f32 atomics) with enough 256 x 256 x split workgroups go
     // to gemm4.hip, the transposed-operand form of the same tile.  CTCLIP_GEMM_NO_V4=1 disables it.
-    static const bool no_v4 = getenv("CTCLIP_GEMM_NO_V4") != nullptr;
+    static const bool no_v4 = CTCLIP_KNOB("CTCLIP_GEMM_NO_V4") != nullptr;
     const long blocks4 = blocks3 * (split_k > 1 ? split_k : 1);
     if (!no_v4 && !force_v1 && !a_kmajor && !b_kmajor && accumulate && c_fp32 && !bias && !resid && (K % 32) == 0 &&
         (blocks4 >= 128 || v2_all))
@@ -492,7 +492,7 @@ int ctclip_vq_topk(const void* A, const void* B, float* part_val, int* part_idx,
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true)) return (int)hipErrorInvalidValue;
   // whole 256-code tiles: the 256 x 256 LDS-DMA form in gemm3.hip (CTCLIP_VQ_NO_V3=1 keeps the kernel below)
-  static const bool no_v3 = getenv("CTCLIP_VQ_NO_V3") != nullptr;
+  static const bool no_v3 = CTCLIP_KNOB("CTCLIP_VQ_NO_V3") != nullptr;
   if (!no_v3 && (M % 256) == 0 && (K % 32) == 0)
     return ctclip_vq_topk3_launch(A, B, part_val, part_idx, M, N, K, lda, ldb, (hipStream_t)stream);
   GemmArgs g{};
@@ -522,7 +522,7 @@ int ctclip_gemm_bf16_geglu(const void* A, const void* Bw, void* H, void* G, int 
   if (M <= 0 || inner <= 0) return 0;
   if ((inner & 63) || K <= 0) return (int)hipErrorInvalidValue;
   const int N = 2 * inner;
-  static const bool no_v3 = getenv("CTCLIP_GEMM_NO_V3") != nullptr;
+  static const bool no_v3 = CTCLIP_KNOB("CTCLIP_GEMM_NO_V3") != nullptr;
   static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
   const long blocks3 = (long)((M + 255) / 256) * ((N + 255) / 256);
   const bool aligned = (ldh & 7) == 0 && (ldg & 7) == 0 && ((((uintptr_t)H) | ((uintptr_t)G)) & 15) == 0;
@@ -537,7 +537,7 @@ int ctclip_gemm_bf16_geglu_bwd(const void* dY, const void* W2T, void* H_dH, void
                                long lddy, long ldw, long ldh, long lddg, void* stream) {
   if (M <= 0 || inner <= 0) return 0;
   if ((inner & 63) || K <= 0) return (int)hipErrorInvalidValue;
-  static const bool no_v3 = getenv("CTCLIP_GEMM_NO_V3") != nullptr;
+  static const bool no_v3 = CTCLIP_KNOB("CTCLIP_GEMM_NO_V3") != nullptr;
   static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
   const long blocks3 = (long)((M + 255) / 256) * ((inner + 255) / 256);
   const bool aligned = (ldh & 7) == 0 && (((uintptr_t)H_dH) & 15) == 0;

@@ -45,6 +45,9 @@ __device__ long g_stamp_cap = 0;
 #define G3_SEG_STORE() do { } while (0)
 #endif
 
+#ifndef G3_NS256
+#define G3_NS256 4
+#endif
 constexpr int BM = 256, BK = 32;
 constexpr int SUB = 16384;                 // the A tile of a stage: 256 x 32 bf16 (the B tile follows it)
 
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
   constexpr bool F32OUT = EPI == 1;
   constexpr int WN = TBN / 64, WM = 8 / WN;            // wave grid: 2 x 4 or 4 x 2
   constexpr int IM = BM / WM / 16, JN = 4;             // MFMA tiles per wave: 8 x 4 or 4 x 4 (the slab is always 64 columns)
-  constexpr int TNS = (TBN == 256) ? 4 : 3;            // ring stages
+  constexpr int TNS = (TBN == 256) ? G3_NS256 : 3;     // ring stages
   constexpr int TSTAGE = SUB + TBN * BK * 2;           // 32 / 24 KiB
   constexpr int TPPW = TSTAGE / 1024 / 8;              // DMA pieces per wave and stage: 4 / 3
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -226,7 +229,8 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
   auto wait_next = [&](int k) {
     if (k + 1 < nk) {
       const int y = nk - 2 - k;
-      if (TNS == 4 && y >= 2) wait_vm<2 * TPPW>();
+      if (TNS >= 5 && y >= 3) wait_vm<3 * TPPW>();
+      else if (TNS >= 4 && y >= 2) wait_vm<2 * TPPW>();
       else if (y >= 1) wait_vm<TPPW>();
       else wait_vm<0>();
     }
@@ -262,7 +266,8 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
       for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
   if (first) {                                      // stage 0 has landed for everybody
     const int y0 = nk - 1;
-    if (TNS == 4 && y0 >= 2) wait_vm<2 * TPPW>();
+    if (TNS >= 5 && y0 >= 3) wait_vm<3 * TPPW>();
+    else if (TNS >= 4 && y0 >= 2) wait_vm<2 * TPPW>();
     else if (y0 >= 1) wait_vm<TPPW>();
     else wait_vm<0>();
   } else if (counted) {
@@ -601,7 +606,7 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
   // shape: 256 x 256 (one workgroup per CU) everywhere but the f32-output products with a very short matrix loop (the
   // out-projection, K = 256: write-back-bound), where two 256 x 128 workgroups per CU overlap one's stores with the other's
   // loop.  CTCLIP_GEMM3_BN=128|256 forces one shape (experiments).
-  static const int forced = [] { const char* e = getenv("CTCLIP_GEMM3_BN"); return e ? atoi(e) : 0; }();
+  static const int forced = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM3_BN"); return e ? atoi(e) : 0; }();
   const int bn = (forced == 128 || forced == 256) ? forced : ((c_fp32 && K <= 256) ? 128 : 256);
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + bn - 1) / bn;
 #define G3_LAUNCH(BN_, EPI_, LDS_)                                                                                        \
@@ -617,7 +622,7 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
   } while (0)
 #define G3_SHAPES(EPI_)                                                                                                   \
   do {                                                                                                                    \
-    if (bn == 256) G3_LAUNCH(256, EPI_, (size_t)4 * (SUB + 256 * BK * 2)); /* 128 KiB: one workgroup per CU */           \
+    if (bn == 256) G3_LAUNCH(256, EPI_, (size_t)G3_NS256 * (SUB + 256 * BK * 2)); /* 128 KiB: one workgroup per CU */           \
     else G3_LAUNCH(128, EPI_, (size_t)3 * (SUB + 128 * BK * 2));           /* 72 KiB: two workgroups per CU */           \
   } while (0)
   static const int cus = [] {
@@ -627,7 +632,7 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
   }();
   const long total = (long)g.tiles_m * g.tiles_n;
   const long resident = (long)cus * (bn == 256 ? 1 : 2);
-  static const bool persist = [] { const char* e = getenv("CTCLIP_GEMM3_PERSIST"); return !e || atoi(e) != 0; }();   // 0: one tile per workgroup (A/B)
+  static const bool persist = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM3_PERSIST"); return !e || atoi(e) != 0; }();   // 0: one tile per workgroup (A/B)
   const int grid = (int)((total < resident || !persist) ? total : resident);
   const int epi = act >= 2 ? act : (c_fp32 ? 1 : 0);
   if (epi == 0) G3_SHAPES(0);

@@ -21,8 +21,10 @@ struct PatchGeom {
   unsigned m_p, m_ptp, m_vpr, m_cpt;   // floor(2^32 / d) + 1 for d = p, pt*p, 16-byte vectors per LDS row, chunks per A row:
 };                                      // x / d == __umulhi(x, m) for x * d < 2^32 (one v_mul_hi instead of a ~40-instruction divide)
 
-__host__ __device__ inline unsigned magic_of(unsigned d) { return (unsigned)(0x100000000ull / d) + 1u; }
-__device__ __forceinline__ int fdiv(int x, unsigned m) { return (int)__umulhi((unsigned)x, m); }
+// d == 1 has no 32-bit magic (2^32 + 1): it is encoded as m = 0 and divides by passing x through (one 16-byte vector per
+// LDS row, or an 8-wide A row, are legal tiny geometries)
+__host__ __device__ inline unsigned magic_of(unsigned d) { return d <= 1u ? 0u : (unsigned)(0x100000000ull / d) + 1u; }
+__device__ __forceinline__ int fdiv(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }
 
 template <typename T> __device__ __forceinline__ float ldf(T v);
 template <> __device__ __forceinline__ float ldf<float>(float v) { return v; }
@@ -349,7 +351,7 @@ bool fast_geom(PatchGeom& g, const void* vol, size_t esz, size_t* lds) {
   const int nrows = g.C * g.pt * g.p;
   // LDS budget per workgroup: small enough for several workgroups per CU, whose load / statistics / store phases then
   // overlap (one 96 KiB workgroup per CU ran them strictly one after the other).  CTCLIP_PATCH_LDS_KB overrides.
-  static const size_t lds_cap = [] { const char* e = getenv("CTCLIP_PATCH_LDS_KB"); return (size_t)(e ? atoi(e) : 32) * 1024; }();   // B=16: 128 KiB 1820/2062 us (fwd/bwd), 48 KiB 1113/959, 32 KiB 1033/967
+  static const size_t lds_cap = [] { const char* e = CTCLIP_KNOB("CTCLIP_PATCH_LDS_KB"); return (size_t)(e ? atoi(e) : 32) * 1024; }();   // B=16: 128 KiB 1820/2062 us (fwd/bwd), 48 KiB 1113/959, 32 KiB 1033/967
   for (int tpb = g.Wt; tpb >= 1; --tpb) {
     if (g.Wt % tpb) continue;
     const size_t rlb = (size_t)tpb * g.p * esz;

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
 
 // plane path geometry: threads (multiple of 64) or 0 when the plane does not fit a workgroup / LDS
 inline int plane_threads(int H, int W, int d, int* strips, size_t* lds) {
-  if (getenv("CTCLIP_PEG_SWEEP")) return 0;
+  if (CTCLIP_KNOB("CTCLIP_PEG_SWEEP")) return 0;
   if ((d / 4) % PL_CG) return 0;
   const int st = (W + PL_P - 1) / PL_P;
   const int items = H * st * PL_CG;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(WG_MAXT) void peg_wgrad_plane_kernel(const float* _
 }
 
 inline int wgrad_plane_threads(int H, int W, int d, int* strips, size_t* lds) {
-  if (getenv("CTCLIP_PEG_SWEEP")) return 0;
+  if (CTCLIP_KNOB("CTCLIP_PEG_SWEEP")) return 0;
   if ((d / 4) % PL_CG) return 0;
   const int st = (W + PL_P - 1) / PL_P;
   const int threads = (H * st * WG_C2 + 63) / 64 * 64;

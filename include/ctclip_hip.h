@@ -7,7 +7,14 @@
  *
  * Conventions
  *   - every function returns a hipError_t as int (0 = success) and only enqueues work on `stream`
- *     (a hipStream_t passed as void*); nothing allocates, synchronises or keeps global state.
+ *     (a hipStream_t passed as void*); nothing allocates or synchronises.  The only process state is
+ *     idempotent: the first launch of a kernel that needs more than 64 KiB of LDS raises that kernel's
+ *     dynamic-LDS limit once (hipFuncSetAttribute), and the CU count is read once.
+ *   - environment: the library reads exactly two variables, both test hooks -- CTCLIP_GEMM_V2_ALL (lower
+ *     the size gates of the pipelined GEMM kernels so that small test shapes reach every kernel) and
+ *     CTCLIP_ATTN_SP_CHUNK (sequences per workgroup of the sequence-persistent attention kernels, for
+ *     ragged-chunk tests).  Results do not depend on either.  Development A/B switches exist only in
+ *     builds compiled with -DCTCLIP_TUNING_KNOBS.
  *   - all pointers are DEVICE pointers owned by the caller; "bf16" buffers are raw uint16 storage.
  *   - matrices are row-major; `ld*` are row strides in ELEMENTS.  bf16 matrices need 16-byte aligned
  *     base pointers and strides that are multiples of 8.
@@ -21,7 +28,8 @@ extern "C" {
 #endif
 
 /* ---- GEMM (MFMA) -------------------------------------------------------------------------------
- * C[M,N] = alpha * opA(A) opB(B) (+bias[N]) (+resid[M,N]) ; act: 0 none, 1 erf-GELU.
+ * C[M,N] = alpha * opA(A) opB(B) (+bias[N]) (+resid[M,N]) ; act: 0 none, 1 erf-GELU (anything else:
+ * hipErrorInvalidValue).
  * a_kmajor=1: A is [M][K]; 0: A is [K][M].  b_kmajor=1: B is [N][K] (nn.Linear weight); 0: [K][N].
  * c_fp32: output f32 instead of bf16.  accumulate=1: C (f32) += result with atomics (caller
  * pre-initialises C; bias/resid added once); split_k>1 splits K over workgroups and needs accumulate.

@@ -526,11 +526,17 @@ def test_volume_ingest_vs_reference_pipeline(hip, H, W, D, xy, z, target, i16):
 
 
 # ---------------------------------------------------------------------------------------------- patch embed
+@pytest.mark.parametrize("geom", [
+    (2, 1, 8, 12, 16, 4, 4),
+    (2, 1, 4, 4, 8, 2, 2),       # tiny: 8 features = ONE 16-byte chunk per A row, and (bf16) one 16-byte vector per LDS row --
+    (2, 1, 4, 4, 4, 2, 2),       # ... (f32, Wx = 4): both multiply-high divisors are 1, which has no 32-bit magic
+    (1, 1, 20, 40, 80, 10, 20),  # the production tubelet (p = 20, pt = 10) on a small volume: divisors 20 / 200 / 30 / 500
+])
 @pytest.mark.parametrize("in16", [False, True])
-def test_patch_ln_forward_and_volume_gradient(hip, in16):
+def test_patch_ln_forward_and_volume_gradient(hip, in16, geom):
     """reference src/utils/ctvit.py:44-49 (Rearrange + LayerNorm over the tubelet) and its gradient w.r.t. the VOLUME
     (ctclip_patch_ln_bwd_dx; used by integrated gradients only), against einops-free torch on the same inputs."""
-    B, C, Dz, Hy, Wx, pt, p = 2, 1, 8, 12, 16, 4, 4
+    B, C, Dz, Hy, Wx, pt, p = geom
     F_ = C * pt * p * p
     vol = rnd(B, C, Dz, Hy, Wx, seed=50)
     if in16:

@@ -1,11 +1,12 @@
 """Run tools/bench_gemm.py under several gemm3 variants (env switches), one subprocess each, and tabulate TFLOP/s."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIAG = os.path.join(ROOT, "ct-clip-ut_amd", "ctclip_hip", "libctclip_hip_diag.so")
 variants = [
-    ("gemm4 lockstep", {"CTCLIP_GEMM4_ROLES": "0"}),
-    ("gemm4 roles", {"CTCLIP_GEMM4_ROLES": "1"}),
-    ("gemm4 lockstep (2)", {"CTCLIP_GEMM4_ROLES": "0"}),
-    ("gemm4 roles (2)", {"CTCLIP_GEMM4_ROLES": "1"}),
+    ("4 stages", {}),
+    ("5 stages (160 KiB)", {"CTCLIP_HIP_LIB": DIAG}),
+    ("4 stages (2)", {}),
+    ("5 stages (2)", {"CTCLIP_HIP_LIB": DIAG}),
 ]
 sel = os.environ.get("VARIANTS")
 if sel:
