@@ -302,7 +302,11 @@ def test_ctclip_training_steps_golden():
         ratio = float(du.norm() / (dr.norm() + 1e-30))
         print(f"  update of {k}: cosine {c:.5f}, length ratio {ratio:.4f} (|update| {float(dr.norm()):.3e})")
         assert c >= 0.97 and 0.97 <= ratio <= 1.03, k
-        check("final " + k, final[k], ref_w, 3e-4)      # sign flips of near-zero gradients move single weights by 2 lr
+        # element-wise: Adam's first steps are ~lr * sign(g), so an element whose (near-zero) gradient has the other sign under
+        # bf16 noise ends up to ~2 lr per step away; nothing may be further off than that
+        worst = float((final[k].detach().cpu() - ref_w).abs().max())
+        print(f"    largest element deviation {worst:.2e} (bound {6 * 1.25e-5:.2e})")
+        assert worst <= 6 * 1.25e-5, k
     # EMA codebook after two training forwards (decay 0.8): free-running codes, so a few rows may differ
     emb, emb_ref = final["visual_transformer.vq._codebook.embed"].cpu(), g["final.visual_transformer.vq._codebook.embed"]
     row_ok = ((emb - emb_ref).abs().amax(-1) <= 1e-3).float().mean()
