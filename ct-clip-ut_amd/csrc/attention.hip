@@ -636,7 +636,9 @@ int ctclip_attn_fwd_dropout(const void* q, const void* k, const void* v, void* o
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
   if (int e = check(a, dhead)) return e;
   {
-    const int e = ctclip_attn_sp_fwd(a, dhead, (hipStream_t)stream);   // long rows: sequence-persistent kernels
+    const int ew = ctclip_attn_ws_fwd(a, dhead, (hipStream_t)stream);  // long rows with a shared bias: a wave per sequence
+    if (ew >= 0) return ew;
+    const int e = ctclip_attn_sp_fwd(a, dhead, (hipStream_t)stream);   // ... or the sequence-persistent kernels
     if (e >= 0) return e;
   }
   const int nw = waves_for(n, dhead);

@@ -31,6 +31,8 @@ typedef CtclipAttnArgs AttnArgs;
 // sequence-persistent kernels for long rows with a shared bias (attention_sp.hip); return -1 when the shape is not
 // eligible and the caller must use the per-sequence kernels of attention.hip.
 int ctclip_attn_sp_fwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
+// wave-owns-the-sequence kernels (attention_ws.hip): same shapes, tried first; -1 = not eligible
+int ctclip_attn_ws_fwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
 int ctclip_attn_sp_bwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
 
 namespace {
