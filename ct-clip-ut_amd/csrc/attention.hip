@@ -685,6 +685,8 @@ int ctclip_attn_bwd_dropout(const void* q, const void* k, const void* v, const v
   a.scale = scale;
   if (int e = check(a, dhead)) return e;
   {
+    const int ew = ctclip_attn_ws_bwd(a, dhead, (hipStream_t)stream);  // a wave per sequence (attention_ws.hip)
+    if (ew >= 0) return ew;
     const int e = ctclip_attn_sp_bwd(a, dhead, (hipStream_t)stream);
     if (e >= 0) return e;
   }

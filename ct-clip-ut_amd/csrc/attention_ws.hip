@@ -253,6 +253,513 @@ int ws_fwd_launch(const AttnArgs& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 1: dQ and delta.  Workgroup = (head, group of QB 32-row query blocks, chunk of sequences); a wave owns whole
+// sequences.  Lane = query, accumulator rows = keys (S^T = K Q^T as in the forward), so lse / delta are one scalar per lane.
+// ------------------------------------------------------------------------------------------------
+// LDS: the bias tiles (fp16, accumulator layout, as the forward) and a 2 x 2 KiB wave-private K image: the K tile arrives
+// from global memory as the score MFMA's operand and is written once more in the swizzled row-major layout the transposing
+// LDS read wants for dQ^T += K^T dS^T.  One K / V fetch serves the QB query blocks.
+// delta[q] = sum_d dO[q][d] O[q][d] is computed here from the dO fragment the wave holds anyway (and stored for the other
+// passes).
+template <bool HAS_BIAS, int QB, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const AttnArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = p.T;
+  const int G = (T + QB - 1) / QB;
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = L % G;
+  L /= G;
+  const int chunk_id = L % p.nchunks, head = L / p.nchunks;
+  const int seq0 = chunk_id * p.chunk, seq1 = min(a.nseq, seq0 + p.chunk);
+  const int nqb = min(QB, T - grp * QB);
+  const int q0 = grp * QB * 32;
+
+  half4_t* bias_l = (half4_t*)smem;                                // [QB][T][4][64] half4
+  char* kimg = smem + (size_t)(HAS_BIAS ? QB * T : 0) * 2048 + (size_t)w * 4096;
+  if (HAS_BIAS) {
+    for (int id = tid; id < QB * T * 256; id += NW * 64) {
+      const int l = id & 63, j = (id >> 6) & 3, bt = id >> 8, t = bt % T, b = bt / T;
+      half4_t hv = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      if (b < nqb) {
+        const float4 v = *(const float4*)(a.bias + ((long)head * a.n + q0 + 32 * b + (l & 31)) * a.n + 32 * t + 8 * j + 4 * (l >> 5));
+        hv[0] = (_Float16)(v.x * p.inv_scale); hv[1] = (_Float16)(v.y * p.inv_scale);
+        hv[2] = (_Float16)(v.z * p.inv_scale); hv[3] = (_Float16)(v.w * p.inv_scale);
+      }
+      bias_l[id] = hv;
+    }
+    __syncthreads();
+  }
+
+  const uint32_t koff = (uint32_t)(r * a.ldk + head * 32 + 8 * half);
+  const uint32_t voff = (uint32_t)(r * a.ldv + head * 32 + 8 * half);
+  const uint32_t qoff = (uint32_t)((q0 + r) * a.ldq + head * 32 + 8 * half);
+  const uint32_t dooff = (uint32_t)((q0 + r) * a.lddo + head * 32 + 8 * half);
+  const uint32_t ooff = (uint32_t)((q0 + r) * a.ldo + head * 32 + 8 * half);
+  const uint32_t kst0 = img_off<32>(r, half), kst1 = img_off<32>(r, 2 + half);
+  const long kseq = (long)a.n * a.ldk, vseq = (long)a.n * a.ldv, qseq = (long)a.n * a.ldq, doseq = (long)a.n * a.lddo,
+             oseq = (long)a.n * a.ldo;
+  const uint32_t ktile = (uint32_t)(32 * a.ldk), vtile = (uint32_t)(32 * a.ldv);
+
+  for (int seq = seq0 + w; seq < seq1; seq += NW) {
+    const bf16_t* kb = a.k + seq * kseq + koff;
+    const bf16_t* vb = a.v + seq * vseq + voff;
+    bf16x8 kr[2][2], vr[2][2];
+    auto request = [&](int slot, int t) {
+      kr[slot][0] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * ktile));
+      kr[slot][1] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * ktile + 16));
+      vr[slot][0] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * vtile));
+      vr[slot][1] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * vtile + 16));
+    };
+    request(0, 0);
+    if (T > 1) request(1, 1);
+    bf16x8 qf[QB][2], df[QB][2];
+    float nlse2[QB], delta[QB];
+    f32x16 dq[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      const uint32_t bo = (uint32_t)(b < nqb ? b : 0) * 32;        // a short last group re-reads block 0 (results discarded)
+      const short8v q0v = *(const short8v*)(a.q + seq * qseq + qoff + bo * a.ldq), q1v = *(const short8v*)(a.q + seq * qseq + qoff + bo * a.ldq + 16);
+      const short8v g0v = *(const short8v*)(a.dO + seq * doseq + dooff + bo * a.lddo), g1v = *(const short8v*)(a.dO + seq * doseq + dooff + bo * a.lddo + 16);
+      const short8v o0v = *(const short8v*)(a.oin + seq * oseq + ooff + bo * a.ldo), o1v = *(const short8v*)(a.oin + seq * oseq + ooff + bo * a.ldo + 16);
+      const long stat = ((long)seq * a.heads + head) * a.n + q0 + bo + r;
+      nlse2[b] = -a.lse[stat] * kLog2e;
+      qf[b][0] = as_bf16x8(q0v); qf[b][1] = as_bf16x8(q1v); df[b][0] = as_bf16x8(g0v); df[b][1] = as_bf16x8(g1v);
+      float dl = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        dl = fmaf(bf16_to_f32((bf16_t)g0v[j]), bf16_to_f32((bf16_t)o0v[j]), dl);
+        dl = fmaf(bf16_to_f32((bf16_t)g1v[j]), bf16_to_f32((bf16_t)o1v[j]), dl);
+      }
+      delta[b] = sum_halves(dl);
+      if (half == 0 && b < nqb) a.delta[stat] = delta[b];
+      zero_acc(dq[b]);
+    }
+
+    auto tile = [&](int slot, int t) {
+      char* ki = kimg + (t & 1) * 2048;
+      const bf16x8 k0 = kr[slot][0], k1 = kr[slot][1], v0 = vr[slot][0], v1 = vr[slot][1];
+      *(bf16x8*)(ki + kst0) = k0;
+      *(bf16x8*)(ki + kst1) = k1;
+      const bf16x8 kt0 = tr_frag<32>(ki, 0, 0, 0, lane), kt1 = tr_frag<32>(ki, 0, 1, 0, lane);
+#pragma unroll
+      for (int b = 0; b < QB; ++b) {
+        f32x16 S, dP;
+        if (HAS_BIAS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const half4_t hb = bias_l[((b * T + t) * 4 + j) * 64 + lane];
+            S[4 * j] = (float)hb[0]; S[4 * j + 1] = (float)hb[1]; S[4 * j + 2] = (float)hb[2]; S[4 * j + 3] = (float)hb[3];
+          }
+        } else {
+          zero_acc(S);
+        }
+        zero_acc(dP);
+        S = mfma32(k0, qf[b][0], S);
+        S = mfma32(k1, qf[b][1], S);
+        dP = mfma32(v0, df[b][0], dP);
+        dP = mfma32(v1, df[b][1], dP);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float pr = exp2_fast(fmaf(S[i], p.c1, nlse2[b]));
+          S[i] = pr * (dP[i] - delta[b]);                           // dS^T[key][q]
+        }
+        const bf16x8 d0 = acc_frag(S, 0), d1 = acc_frag(S, 1);
+        dq[b] = mfma32(kt0, d0, dq[b]);
+        dq[b] = mfma32(kt1, d1, dq[b]);
+        __builtin_amdgcn_sched_barrier(0);                         // one block's temporaries live at a time
+      }
+      if (t + 2 < T) request(slot, t + 2);                         // a whole tile of work ahead of its use
+    };
+    int t = 0;
+    for (; t + 1 < T; t += 2) {
+      tile(0, t);
+      tile(1, t + 1);
+    }
+    if (t < T) tile(0, t);
+
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      if (b >= nqb) continue;
+      const f32x16 dd[1] = {dq[b]};
+      store_rows<32>(a.dq + ((long)seq * a.n + q0 + 32 * b + r) * a.lddq + head * 32, dd, a.scale, lane);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 1b: d(bias)[head][q][key] = sum over sequences of dS.  The sum needs an owner per (query block, key tile):
+// adding the waves' dS into shared LDS tiles with ds_add_f32 was measured at ~190 cycles per wave-instruction (25 ms per
+// call), so here -- and only here -- the waves of a workgroup split the KEY TILES instead of the sequences and keep their
+// tiles' sums in registers across the whole chunk:
+//   workgroup = (head, pair of 32-row query blocks, chunk of sequences), 8 waves: wave w owns query block (w & 1) and key
+//   tiles (w >> 1) + 4 j.  Per sequence the workgroup stages K, V (whole rows of the head) and the two Q / dO blocks into
+//   swizzled LDS images (prefetched into registers during the previous sequence), two barriers per sequence, no exchange.
+// The bias tiles of both blocks sit in LDS as fp16 in accumulator layout, as in the other passes.  delta comes from pass 1.
+// ------------------------------------------------------------------------------------------------
+template <bool HAS_BIAS, int TPW, int NPK>
+__global__ __launch_bounds__(512, 1) void ws_bwd_dbias_kernel(WsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const AttnArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = p.T;
+  const int G2 = (T + 1) / 2;
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int pair = L % G2;
+  L /= G2;
+  const int chunk_id = L % p.nchunks, head = L / p.nchunks;
+  const int seq0 = chunk_id * p.chunk, seq1 = min(a.nseq, seq0 + p.chunk);
+  const int b = w & 1, g = w >> 1;
+  const bool own = 2 * pair + b < T;                               // an odd T leaves the last pair with one block
+  const int q0 = (2 * pair + (own ? b : 0)) * 32;
+
+  char* kimg = smem;                                               // [n][32] bf16
+  char* vimg = smem + (size_t)a.n * 64;                            // [n][32] bf16
+  char* qd = smem + (size_t)a.n * 128;                             // 2 blocks x {Q [32][32], dO [32][32]} bf16
+
+  half4_t* bias_l = (half4_t*)(smem + (size_t)a.n * 128 + 8192);   // [2][T][4][64] half4, accumulator layout as the forward
+  if (HAS_BIAS)
+    for (int id = tid; id < 2 * T * 256; id += 512) {
+      const int l = id & 63, j = (id >> 6) & 3, bt = id >> 8, t = bt % T, bb = bt / T;
+      half4_t hv = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      if (2 * pair + bb < T) {
+        const float4 v = *(const float4*)(a.bias + ((long)head * a.n + (2 * pair + bb) * 32 + (l & 31)) * a.n + 32 * t + 8 * j + 4 * (l >> 5));
+        hv[0] = (_Float16)(v.x * p.inv_scale); hv[1] = (_Float16)(v.y * p.inv_scale);
+        hv[2] = (_Float16)(v.z * p.inv_scale); hv[3] = (_Float16)(v.w * p.inv_scale);
+      }
+      bias_l[id] = hv;
+    }
+  f32x16 dbacc[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) zero_acc(dbacc[j]);
+
+  // staging: thread `tid` moves 16-byte pieces tid + 512 i of K and of V (piece = row * 4 + chunk) and one piece of Q / dO
+  const int npk = a.n * 4;
+  const int qd_blk = tid >> 8, qd_which = (tid >> 7) & 1, qd_row = (tid & 127) >> 2, qd_c = tid & 3;
+  const int qd_q = (2 * pair + (2 * pair + qd_blk < T ? qd_blk : 0)) * 32 + qd_row;
+  const uint32_t qd_src = qd_which ? (uint32_t)(qd_q * a.lddo + head * 32 + qd_c * 8) : (uint32_t)(qd_q * a.ldq + head * 32 + qd_c * 8);
+  const uint32_t qd_dst = (uint32_t)(qd_blk * 4096 + qd_which * 2048) + img_off<32>(qd_row, qd_c);
+  const long kseq = (long)a.n * a.ldk, vseq = (long)a.n * a.ldv, qseq = (long)a.n * a.ldq, doseq = (long)a.n * a.lddo;
+  const long stat0 = (long)head * a.n + q0 + r, statseq = (long)a.heads * a.n;
+
+  u32x4 kst[NPK], vst[NPK], qdst = {0u, 0u, 0u, 0u};
+  float nlse2 = 0.f, delta = 0.f, nlse2_n = 0.f, delta_n = 0.f;
+  auto ld_staged = [&](long seq) {
+    const bf16_t* kb = a.k + seq * kseq + head * 32;
+    const bf16_t* vb = a.v + seq * vseq + head * 32;
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) {
+      const int id = tid + 512 * i;
+      if (id < npk) {
+        kst[i] = *(const u32x4*)(kb + (uint32_t)((id >> 2) * a.ldk + (id & 3) * 8));
+        vst[i] = *(const u32x4*)(vb + (uint32_t)((id >> 2) * a.ldv + (id & 3) * 8));
+      }
+    }
+    qdst = qd_which ? *(const u32x4*)(a.dO + seq * doseq + qd_src) : *(const u32x4*)(a.q + seq * qseq + qd_src);
+    nlse2_n = -a.lse[seq * statseq + stat0] * kLog2e;
+    delta_n = a.delta[seq * statseq + stat0];
+  };
+  auto st_staged = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPK; ++i) {
+      const int id = tid + 512 * i;
+      if (id < npk) {
+        *(u32x4*)(kimg + img_off<32>(id >> 2, id & 3)) = kst[i];
+        *(u32x4*)(vimg + img_off<32>(id >> 2, id & 3)) = vst[i];
+      }
+    }
+    *(u32x4*)(qd + qd_dst) = qdst;
+    nlse2 = nlse2_n;
+    delta = delta_n;
+  };
+
+  ld_staged(seq0);
+  st_staged();
+  __syncthreads();
+  for (int seq = seq0; seq < seq1; ++seq) {
+    const bf16x8 qf0 = row_frag<32>(qd + b * 4096, 0, 0, lane), qf1 = row_frag<32>(qd + b * 4096, 0, 1, lane);
+    const bf16x8 df0 = row_frag<32>(qd + b * 4096 + 2048, 0, 0, lane), df1 = row_frag<32>(qd + b * 4096 + 2048, 0, 1, lane);
+    ld_staged(seq + 1 < seq1 ? seq + 1 : seq);                     // consumed after this sequence's tiles
+    if (own) {
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int t = g + 4 * j;
+        if (t < T) {
+          f32x16 S, dP;
+          if (HAS_BIAS) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const half4_t hb = bias_l[((b * T + t) * 4 + jj) * 64 + lane];
+              S[4 * jj] = (float)hb[0]; S[4 * jj + 1] = (float)hb[1]; S[4 * jj + 2] = (float)hb[2]; S[4 * jj + 3] = (float)hb[3];
+            }
+          } else {
+            zero_acc(S);
+          }
+          zero_acc(dP);
+          S = mfma32(row_frag<32>(kimg, 32 * t, 0, lane), qf0, S);
+          S = mfma32(row_frag<32>(kimg, 32 * t, 1, lane), qf1, S);
+          dP = mfma32(row_frag<32>(vimg, 32 * t, 0, lane), df0, dP);
+          dP = mfma32(row_frag<32>(vimg, 32 * t, 1, lane), df1, dP);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float pr = exp2_fast(fmaf(S[i], p.c1, nlse2));
+            dbacc[j][i] = fmaf(pr, dP[i] - delta, dbacc[j][i]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();                                               // every wave is done with the images
+    st_staged();
+    __syncthreads();
+  }
+
+  // flush: dense rows, or the relative-position table through an LDS copy of it (the images are idle now)
+  const int q = q0 + r;
+  if (a.dbias_dense) {
+    if (own)
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int t = g + 4 * j;
+        if (t < T)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            atomicAdd(a.dbias_dense + ((long)head * a.n + q) * a.n + 32 * t + acc_row(i, half), dbacc[j][i]);
+      }
+  } else {
+    float* table = (float*)smem;
+    for (int i = tid; i < a.table_size; i += 512) table[i] = 0.f;
+    __syncthreads();
+    if (own) {
+      const int yq = a.grid_w > 0 ? q / a.grid_w : 0, xq = a.grid_w > 0 ? q % a.grid_w : 0;
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int t = g + 4 * j;
+        if (t < T)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = 32 * t + acc_row(i, half);
+            int ti;
+            if (a.grid_w > 0) {
+              const int yk = key / a.grid_w, xk = key % a.grid_w;
+              ti = (yq - yk + a.grid_h - 1) * (2 * a.grid_w - 1) + (xq - xk + a.grid_w - 1);
+            } else {
+              ti = a.relidx[(long)q * a.n + key];
+            }
+            atomicAdd(&table[ti], dbacc[j][i]);
+          }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < a.table_size; i += 512) {
+      const float v = table[i];
+      if (v != 0.f) atomicAdd(a.dbias_table + (long)head * a.table_size + i, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 2: dK, dV.  Workgroup = (head, group of KB 32-key blocks, chunk of sequences); a wave owns whole sequences.
+// Lane = key, accumulator rows = queries: P and dS come out as the B operands of dV^T += dO^T P and dK^T += Q^T dS.
+// ------------------------------------------------------------------------------------------------
+// The K / V fragments of the key blocks are fixed for a sequence; Q and dO tiles stream from global memory as MFMA operands
+// (one fetch serves the KB key blocks: at KB = 1 the kernel is bound by the half-used 128-byte lines of those fetches, like
+// the forward) and are written once more into a wave-private swizzled image for the transposing reads.
+// -lse log2(e) and delta vary along the accumulator ROWS here, so each wave first copies its sequence's two stat rows into
+// LDS and reads them back four at a time (broadcast reads, shared by the KB blocks).
+template <bool HAS_BIAS, int KB, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dkv_kernel(WsArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const AttnArgs& a = p.a;
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, half = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = p.T;
+  const int G = (T + KB - 1) / KB;
+  int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = L % G;
+  L /= G;
+  const int chunk_id = L % p.nchunks, head = L / p.nchunks;
+  const int seq0 = chunk_id * p.chunk, seq1 = min(a.nseq, seq0 + p.chunk);
+  const int nkb = min(KB, T - grp * KB);
+  const int key0 = grp * KB * 32;
+
+  half4_t* bias_l = (half4_t*)smem;                                // [KB][T][4][64] half4: bias[q rows of the registers][key]
+  char* wave_l = smem + (size_t)(HAS_BIAS ? KB * T : 0) * 2048 + (size_t)w * (4096 + (size_t)a.n * 8);
+  char* qimg = wave_l;                                             // [32 q][32 d] bf16
+  char* doimg = wave_l + 2048;                                     // [32 q][32 d] bf16
+  float* stat_l = (float*)(wave_l + 4096);                         // [n] -lse log2e, [n] delta
+  if (HAS_BIAS) {
+    for (int id = tid; id < KB * T * 256; id += NW * 64) {
+      const int l = id & 63, j = (id >> 6) & 3, bt = id >> 8, t = bt % T, b = bt / T;
+      half4_t hv = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      if (b < nkb) {
+        const float* bp = a.bias + ((long)head * a.n + 32 * t + 8 * j + 4 * (l >> 5)) * a.n + key0 + 32 * b + (l & 31);
+        hv[0] = (_Float16)(bp[0] * p.inv_scale); hv[1] = (_Float16)(bp[a.n] * p.inv_scale);
+        hv[2] = (_Float16)(bp[2 * (long)a.n] * p.inv_scale); hv[3] = (_Float16)(bp[3 * (long)a.n] * p.inv_scale);
+      }
+      bias_l[id] = hv;
+    }
+    __syncthreads();
+  }
+
+  const uint32_t koff = (uint32_t)((key0 + r) * a.ldk + head * 32 + 8 * half);
+  const uint32_t voff = (uint32_t)((key0 + r) * a.ldv + head * 32 + 8 * half);
+  const uint32_t qoff = (uint32_t)(r * a.ldq + head * 32 + 8 * half);
+  const uint32_t dooff = (uint32_t)(r * a.lddo + head * 32 + 8 * half);
+  const uint32_t ist0 = img_off<32>(r, half), ist1 = img_off<32>(r, 2 + half);
+  const long kseq = (long)a.n * a.ldk, vseq = (long)a.n * a.ldv, qseq = (long)a.n * a.ldq, doseq = (long)a.n * a.lddo;
+  const uint32_t qtile = (uint32_t)(32 * a.ldq), dotile = (uint32_t)(32 * a.lddo);
+  const uint32_t kblk = (uint32_t)(32 * a.ldk), vblk = (uint32_t)(32 * a.ldv);
+
+  for (int seq = seq0 + w; seq < seq1; seq += NW) {
+    const bf16_t* qb = a.q + seq * qseq + qoff;
+    const bf16_t* dob = a.dO + seq * doseq + dooff;
+    bf16x8 qr[2][2], gr[2][2];
+    auto request = [&](int slot, int t) {
+      qr[slot][0] = as_bf16x8(*(const short8v*)(qb + (uint32_t)t * qtile));
+      qr[slot][1] = as_bf16x8(*(const short8v*)(qb + (uint32_t)t * qtile + 16));
+      gr[slot][0] = as_bf16x8(*(const short8v*)(dob + (uint32_t)t * dotile));
+      gr[slot][1] = as_bf16x8(*(const short8v*)(dob + (uint32_t)t * dotile + 16));
+    };
+    bf16x8 kf[KB][2], vf[KB][2];
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+      const uint32_t bo = (uint32_t)(b < nkb ? b : 0);             // a short last group re-reads block 0 (results discarded)
+      const bf16_t* kp = a.k + seq * kseq + koff + bo * kblk;
+      const bf16_t* vp = a.v + seq * vseq + voff + bo * vblk;
+      kf[b][0] = as_bf16x8(*(const short8v*)kp);
+      kf[b][1] = as_bf16x8(*(const short8v*)(kp + 16));
+      vf[b][0] = as_bf16x8(*(const short8v*)vp);
+      vf[b][1] = as_bf16x8(*(const short8v*)(vp + 16));
+    }
+    request(0, 0);
+    if (T > 1) request(1, 1);
+    {
+      const long stat = ((long)seq * a.heads + head) * a.n;
+      for (int i = lane; i < a.n; i += 64) {
+        stat_l[i] = -a.lse[stat + i] * kLog2e;
+        stat_l[a.n + i] = a.delta[stat + i];
+      }
+    }
+    f32x16 dk[KB], dv[KB];
+#pragma unroll
+    for (int b = 0; b < KB; ++b) { zero_acc(dk[b]); zero_acc(dv[b]); }
+
+    auto tile = [&](int slot, int t) {
+      const bf16x8 q0 = qr[slot][0], q1 = qr[slot][1], g0 = gr[slot][0], g1 = gr[slot][1];
+      asm volatile("" ::: "memory");                               // the image is single: the previous tile's reads stay above
+      *(bf16x8*)(qimg + ist0) = q0;
+      *(bf16x8*)(qimg + ist1) = q1;
+      *(bf16x8*)(doimg + ist0) = g0;
+      *(bf16x8*)(doimg + ist1) = g1;
+      const bf16x8 gt0 = tr_frag<32>(doimg, 0, 0, 0, lane), gt1 = tr_frag<32>(doimg, 0, 1, 0, lane);
+      const bf16x8 qt0 = tr_frag<32>(qimg, 0, 0, 0, lane), qt1 = tr_frag<32>(qimg, 0, 1, 0, lane);
+#pragma unroll
+      for (int b = 0; b < KB; ++b) {
+        f32x16 S, dP;
+        if (HAS_BIAS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const half4_t hb = bias_l[((b * T + t) * 4 + j) * 64 + lane];
+            S[4 * j] = (float)hb[0]; S[4 * j + 1] = (float)hb[1]; S[4 * j + 2] = (float)hb[2]; S[4 * j + 3] = (float)hb[3];
+          }
+        } else {
+          zero_acc(S);
+        }
+        zero_acc(dP);
+        S = mfma32(q0, kf[b][0], S);                               // S[q][key]
+        S = mfma32(q1, kf[b][1], S);
+        dP = mfma32(g0, vf[b][0], dP);                             // dP[q][key]
+        dP = mfma32(g1, vf[b][1], dP);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 l4 = *(const float4*)(stat_l + 32 * t + 8 * g + 4 * half);
+          const float4 d4 = *(const float4*)(stat_l + a.n + 32 * t + 8 * g + 4 * half);
+          const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float pr = exp2_fast(fmaf(S[4 * g + i], p.c1, ls[i]));
+            S[4 * g + i] = pr;
+            dP[4 * g + i] = pr * (dP[4 * g + i] - de[i]);
+          }
+        }
+        const bf16x8 p0 = acc_frag(S, 0), p1 = acc_frag(S, 1), d0 = acc_frag(dP, 0), d1 = acc_frag(dP, 1);
+        dv[b] = mfma32(gt0, p0, dv[b]);
+        dv[b] = mfma32(gt1, p1, dv[b]);
+        dk[b] = mfma32(qt0, d0, dk[b]);
+        dk[b] = mfma32(qt1, d1, dk[b]);
+        __builtin_amdgcn_sched_barrier(0);                         // one block's temporaries live at a time
+      }
+      if (t + 2 < T) request(slot, t + 2);                         // a whole tile of work ahead of its use
+    };
+    int t = 0;
+    for (; t + 1 < T; t += 2) {
+      tile(0, t);
+      tile(1, t + 1);
+    }
+    if (t < T) tile(0, t);
+
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+      if (b >= nkb) continue;
+      const long row = (long)seq * a.n + key0 + 32 * b + r;
+      const f32x16 kk[1] = {dk[b]}, vv[1] = {dv[b]};
+      store_rows<32>(a.dk + row * a.lddk + head * 32, kk, a.scale, lane);
+      store_rows<32>(a.dv + row * a.lddv + head * 32, vv, 1.0f, lane);
+    }
+  }
+}
+
+template <typename K>
+int ws_launch(K kernel, const WsArgs& p, int nblocks, int nw, size_t lds, hipStream_t st) {
+  if (lds > 160 * 1024) return -1;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(nw * 64), lds, st, p);
+  return (int)hipGetLastError();
+}
+
+template <int NW, int QB, int KB>
+int ws_bwd_launch(const AttnArgs& a, hipStream_t st) {
+  int nb1 = 0, nb2 = 0, nb3 = 0;
+  const WsArgs p1 = ws_plan(a, QB, NW, &nb1);
+  const WsArgs p2 = ws_plan(a, KB, NW, &nb2);
+  WsArgs p3 = ws_plan(a, 2, 1, &nb3);                              // d(bias): every wave walks the whole chunk
+  const bool table = a.dbias_table != nullptr, dense = a.dbias_dense != nullptr;
+  const bool hb = a.bias != nullptr, db = table || dense;
+  const size_t lds1 = (size_t)(hb ? QB * p1.T : 0) * 2048 + (size_t)NW * 4096;
+  const size_t lds2 = (size_t)(hb ? KB * p2.T : 0) * 2048 + (size_t)NW * (4096 + (size_t)a.n * 8);
+  const size_t lds3 = (size_t)a.n * 128 + 8192 + (size_t)(hb ? 2 * p3.T : 0) * 2048;
+  if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return -1;
+  if (db) {
+    if (p3.T > 20 || lds3 > 160 * 1024) return -1;                 // 5 tiles and 5 staged pieces per wave at most
+    if (table && (size_t)a.table_size * 4 > (size_t)a.n * 128) return -1;
+    if (table && a.grid_w <= 0 && !a.relidx) return -1;
+  }
+  int e = hb ? ws_launch(ws_bwd_dq_kernel<true, QB, NW>, p1, nb1, NW, lds1, st)
+             : ws_launch(ws_bwd_dq_kernel<false, QB, NW>, p1, nb1, NW, lds1, st);
+  if (e) return e;
+  if (db) {
+    const int tpw = (p3.T + 3) / 4;
+    if (hb) {
+      e = tpw <= 3 ? ws_launch(ws_bwd_dbias_kernel<true, 3, 5>, p3, nb3, 8, lds3, st)
+                   : ws_launch(ws_bwd_dbias_kernel<true, 5, 5>, p3, nb3, 8, lds3, st);
+    } else {
+      e = ws_launch(ws_bwd_dbias_kernel<false, 5, 5>, p3, nb3, 8, lds3, st);
+    }
+    if (e) return e;
+  }
+  return hb ? ws_launch(ws_bwd_dkv_kernel<true, KB, NW>, p2, nb2, NW, lds2, st)
+            : ws_launch(ws_bwd_dkv_kernel<false, KB, NW>, p2, nb2, NW, lds2, st);
+}
+
 }  // namespace
 
 // -1: shape not eligible, the caller falls back to attention_sp.hip / attention.hip
@@ -269,4 +776,14 @@ int ctclip_attn_ws_fwd(const CtclipAttnArgs& a, int dhead, hipStream_t st) {
 #endif
   (void)qb;
   return ws_fwd_launch<2, 8, 2>(a, st);
+}
+
+// dQ, dK, dV, d(bias) and delta for the same shapes; -1 = not eligible (nothing was launched)
+int ctclip_attn_ws_bwd(const CtclipAttnArgs& a, int dhead, hipStream_t st) {
+  if (!ws_shape_ok(a, dhead)) return -1;
+  if (CTCLIP_KNOB("CTCLIP_ATTN_NO_WS_BWD")) return -1;
+#ifdef CTCLIP_TUNING_KNOBS
+  if (CTCLIP_KNOB("CTCLIP_ATTN_WS_KB1")) return ws_bwd_launch<8, 1, 1>(a, st);
+#endif
+  return ws_bwd_launch<8, 2, 2>(a, st);
 }

@@ -34,6 +34,7 @@ int ctclip_attn_sp_fwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
 // wave-owns-the-sequence kernels (attention_ws.hip): same shapes, tried first; -1 = not eligible
 int ctclip_attn_ws_fwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
 int ctclip_attn_sp_bwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
+int ctclip_attn_ws_bwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
 
 namespace {
 
