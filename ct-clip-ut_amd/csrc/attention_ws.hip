@@ -263,7 +263,7 @@ int ws_fwd_launch(const AttnArgs& a, hipStream_t st) {
 // LDS read wants for dQ^T += K^T dS^T.  One K / V fetch serves the QB query blocks.
 // delta[q] = sum_d dO[q][d] O[q][d] is computed here from the dO fragment the wave holds anyway (and stored for the other
 // passes).
-template <bool HAS_BIAS, int QB, int NW>
+template <bool HAS_BIAS, int QB, int NW, bool ROWLD>
 __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnArgs& a = p.a;
@@ -280,7 +280,8 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
   const int q0 = grp * QB * 32;
 
   half4_t* bias_l = (half4_t*)smem;                                // [QB][T][4][64] half4
-  char* kimg = smem + (size_t)(HAS_BIAS ? QB * T : 0) * 2048 + (size_t)w * 4096;
+  char* kimg = smem + (size_t)(HAS_BIAS ? QB * T : 0) * 2048 + (size_t)w * (ROWLD ? 8192 : 4096);
+  char* vimg = kimg + 4096;                                        // ROWLD only
   if (HAS_BIAS) {
     for (int id = tid; id < QB * T * 256; id += NW * 64) {
       const int l = id & 63, j = (id >> 6) & 3, bt = id >> 8, t = bt % T, b = bt / T;
@@ -295,12 +296,17 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
     __syncthreads();
   }
 
-  const uint32_t koff = (uint32_t)(r * a.ldk + head * 32 + 8 * half);
-  const uint32_t voff = (uint32_t)(r * a.ldv + head * 32 + 8 * half);
+  // ROWLD: a tile is fetched as 16 whole 64-byte rows per wave-instruction (4 lanes per row) -- half the cache lines per
+  // instruction of the fragment pattern (32 rows x 32 bytes) -- and both operands are read back from the LDS image
+  const int crow = lane >> 2, ccol = lane & 3;
+  const uint32_t koff = ROWLD ? (uint32_t)(crow * a.ldk + head * 32 + ccol * 8) : (uint32_t)(r * a.ldk + head * 32 + 8 * half);
+  const uint32_t voff = ROWLD ? (uint32_t)(crow * a.ldv + head * 32 + ccol * 8) : (uint32_t)(r * a.ldv + head * 32 + 8 * half);
+  const uint32_t kstep = ROWLD ? (uint32_t)(16 * a.ldk) : 16u, vstep = ROWLD ? (uint32_t)(16 * a.ldv) : 16u;
   const uint32_t qoff = (uint32_t)((q0 + r) * a.ldq + head * 32 + 8 * half);
   const uint32_t dooff = (uint32_t)((q0 + r) * a.lddo + head * 32 + 8 * half);
   const uint32_t ooff = (uint32_t)((q0 + r) * a.ldo + head * 32 + 8 * half);
-  const uint32_t kst0 = img_off<32>(r, half), kst1 = img_off<32>(r, 2 + half);
+  const uint32_t kst0 = ROWLD ? img_off<32>(crow, ccol) : img_off<32>(r, half);
+  const uint32_t kst1 = ROWLD ? kst0 + 1024 : img_off<32>(r, 2 + half);   // sixteen rows further: same swizzle
   const long kseq = (long)a.n * a.ldk, vseq = (long)a.n * a.ldv, qseq = (long)a.n * a.ldq, doseq = (long)a.n * a.lddo,
              oseq = (long)a.n * a.ldo;
   const uint32_t ktile = (uint32_t)(32 * a.ldk), vtile = (uint32_t)(32 * a.ldv);
@@ -311,9 +317,9 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
     bf16x8 kr[2][2], vr[2][2];
     auto request = [&](int slot, int t) {
       kr[slot][0] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * ktile));
-      kr[slot][1] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * ktile + 16));
+      kr[slot][1] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * ktile + kstep));
       vr[slot][0] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * vtile));
-      vr[slot][1] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * vtile + 16));
+      vr[slot][1] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * vtile + vstep));
     };
     request(0, 0);
     if (T > 1) request(1, 1);
@@ -342,36 +348,48 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
 
     auto tile = [&](int slot, int t) {
       char* ki = kimg + (t & 1) * 2048;
-      const bf16x8 k0 = kr[slot][0], k1 = kr[slot][1], v0 = vr[slot][0], v1 = vr[slot][1];
+      bf16x8 k0 = kr[slot][0], k1 = kr[slot][1], v0 = vr[slot][0], v1 = vr[slot][1];
       *(bf16x8*)(ki + kst0) = k0;
       *(bf16x8*)(ki + kst1) = k1;
+      if (ROWLD) {
+        char* vi = vimg + (t & 1) * 2048;
+        *(bf16x8*)(vi + kst0) = v0;
+        *(bf16x8*)(vi + kst1) = v1;
+        k0 = row_frag<32>(ki, 0, 0, lane); k1 = row_frag<32>(ki, 0, 1, lane);
+        v0 = row_frag<32>(vi, 0, 0, lane); v1 = row_frag<32>(vi, 0, 1, lane);
+      }
       const bf16x8 kt0 = tr_frag<32>(ki, 0, 0, 0, lane), kt1 = tr_frag<32>(ki, 0, 1, 0, lane);
+      // all score / dP MFMAs of the tile first: block 1's run on the matrix pipe while block 0's exponentials issue
+      f32x16 S[QB], dP[QB];
 #pragma unroll
       for (int b = 0; b < QB; ++b) {
-        f32x16 S, dP;
         if (HAS_BIAS) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const half4_t hb = bias_l[((b * T + t) * 4 + j) * 64 + lane];
-            S[4 * j] = (float)hb[0]; S[4 * j + 1] = (float)hb[1]; S[4 * j + 2] = (float)hb[2]; S[4 * j + 3] = (float)hb[3];
+            S[b][4 * j] = (float)hb[0]; S[b][4 * j + 1] = (float)hb[1]; S[b][4 * j + 2] = (float)hb[2]; S[b][4 * j + 3] = (float)hb[3];
           }
         } else {
-          zero_acc(S);
+          zero_acc(S[b]);
         }
-        zero_acc(dP);
-        S = mfma32(k0, qf[b][0], S);
-        S = mfma32(k1, qf[b][1], S);
-        dP = mfma32(v0, df[b][0], dP);
-        dP = mfma32(v1, df[b][1], dP);
+        zero_acc(dP[b]);
+        S[b] = mfma32(k0, qf[b][0], S[b]);
+        S[b] = mfma32(k1, qf[b][1], S[b]);
+        dP[b] = mfma32(v0, df[b][0], dP[b]);
+        dP[b] = mfma32(v1, df[b][1], dP[b]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < QB; ++b) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float pr = exp2_fast(fmaf(S[i], p.c1, nlse2[b]));
-          S[i] = pr * (dP[i] - delta[b]);                           // dS^T[key][q]
+          const float pr = exp2_fast(fmaf(S[b][i], p.c1, nlse2[b]));
+          S[b][i] = pr * (dP[b][i] - delta[b]);                     // dS^T[key][q]
         }
-        const bf16x8 d0 = acc_frag(S, 0), d1 = acc_frag(S, 1);
+        const bf16x8 d0 = acc_frag(S[b], 0), d1 = acc_frag(S[b], 1);
         dq[b] = mfma32(kt0, d0, dq[b]);
         dq[b] = mfma32(kt1, d1, dq[b]);
-        __builtin_amdgcn_sched_barrier(0);                         // one block's temporaries live at a time
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (t + 2 < T) request(slot, t + 2);                         // a whole tile of work ahead of its use
     };
@@ -726,7 +744,7 @@ int ws_launch(K kernel, const WsArgs& p, int nblocks, int nw, size_t lds, hipStr
   return (int)hipGetLastError();
 }
 
-template <int NW, int QB, int KB>
+template <int NW, int QB, int KB, bool ROWLD>
 int ws_bwd_launch(const AttnArgs& a, hipStream_t st) {
   int nb1 = 0, nb2 = 0, nb3 = 0;
   const WsArgs p1 = ws_plan(a, QB, NW, &nb1);
@@ -734,7 +752,7 @@ int ws_bwd_launch(const AttnArgs& a, hipStream_t st) {
   WsArgs p3 = ws_plan(a, 2, 1, &nb3);                              // d(bias): every wave walks the whole chunk
   const bool table = a.dbias_table != nullptr, dense = a.dbias_dense != nullptr;
   const bool hb = a.bias != nullptr, db = table || dense;
-  const size_t lds1 = (size_t)(hb ? QB * p1.T : 0) * 2048 + (size_t)NW * 4096;
+  const size_t lds1 = (size_t)(hb ? QB * p1.T : 0) * 2048 + (size_t)NW * (ROWLD ? 8192 : 4096);
   const size_t lds2 = (size_t)(hb ? KB * p2.T : 0) * 2048 + (size_t)NW * (4096 + (size_t)a.n * 8);
   const size_t lds3 = (size_t)a.n * 128 + 8192 + (size_t)(hb ? 2 * p3.T : 0) * 2048;
   if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return -1;
@@ -743,8 +761,8 @@ int ws_bwd_launch(const AttnArgs& a, hipStream_t st) {
     if (table && (size_t)a.table_size * 4 > (size_t)a.n * 128) return -1;
     if (table && a.grid_w <= 0 && !a.relidx) return -1;
   }
-  int e = hb ? ws_launch(ws_bwd_dq_kernel<true, QB, NW>, p1, nb1, NW, lds1, st)
-             : ws_launch(ws_bwd_dq_kernel<false, QB, NW>, p1, nb1, NW, lds1, st);
+  int e = hb ? ws_launch(ws_bwd_dq_kernel<true, QB, NW, ROWLD>, p1, nb1, NW, lds1, st)
+             : ws_launch(ws_bwd_dq_kernel<false, QB, NW, ROWLD>, p1, nb1, NW, lds1, st);
   if (e) return e;
   if (db) {
     const int tpw = (p3.T + 3) / 4;
@@ -783,7 +801,8 @@ int ctclip_attn_ws_bwd(const CtclipAttnArgs& a, int dhead, hipStream_t st) {
   if (!ws_shape_ok(a, dhead)) return -1;
   if (CTCLIP_KNOB("CTCLIP_ATTN_NO_WS_BWD")) return -1;
 #ifdef CTCLIP_TUNING_KNOBS
-  if (CTCLIP_KNOB("CTCLIP_ATTN_WS_KB1")) return ws_bwd_launch<8, 1, 1>(a, st);
+  if (CTCLIP_KNOB("CTCLIP_ATTN_WS_KB1")) return ws_bwd_launch<8, 1, 1, false>(a, st);
+  if (CTCLIP_KNOB("CTCLIP_ATTN_WS_FRAGLD")) return ws_bwd_launch<8, 2, 2, false>(a, st);
 #endif
-  return ws_bwd_launch<8, 2, 2>(a, st);
+  return ws_bwd_launch<8, 2, 2, true>(a, st);
 }
