@@ -414,13 +414,13 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
 // adding the waves' dS into shared LDS tiles with ds_add_f32 was measured at ~190 cycles per wave-instruction (25 ms per
 // call), so here -- and only here -- the waves of a workgroup split the KEY TILES instead of the sequences and keep their
 // tiles' sums in registers across the whole chunk:
-//   workgroup = (head, pair of 32-row query blocks, chunk of sequences), 8 waves: wave w owns query block (w & 1) and key
-//   tiles (w >> 1) + 4 j.  Per sequence the workgroup stages K, V (whole rows of the head) and the two Q / dO blocks into
+//   workgroup = (head, pair of 32-row query blocks, chunk of sequences), NW = 12 (or 8) waves: wave w owns query block
+//   (w & 1) and key tiles (w >> 1) + (NW / 2) j -- three tiles each at n = 576 with 12 waves.  Per sequence the workgroup stages K, V (whole rows of the head) and the two Q / dO blocks into
 //   swizzled LDS images (prefetched into registers during the previous sequence), two barriers per sequence, no exchange.
 // The bias tiles of both blocks sit in LDS as fp16 in accumulator layout, as in the other passes.  delta comes from pass 1.
 // ------------------------------------------------------------------------------------------------
-template <bool HAS_BIAS, int TPW, int NPK>
-__global__ __launch_bounds__(512, 1) void ws_bwd_dbias_kernel(WsArgs p) {
+template <bool HAS_BIAS, int TPW, int NPK, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dbias_kernel(WsArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, half = lane >> 5;
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(512, 1) void ws_bwd_dbias_kernel(WsArgs p) {
   L /= G2;
   const int chunk_id = L % p.nchunks, head = L / p.nchunks;
   const int seq0 = chunk_id * p.chunk, seq1 = min(a.nseq, seq0 + p.chunk);
+  constexpr int NT = NW * 64, G = NW / 2;                         // threads; key-tile groups
   const int b = w & 1, g = w >> 1;
   const bool own = 2 * pair + b < T;                               // an odd T leaves the last pair with one block
   const int q0 = (2 * pair + (own ? b : 0)) * 32;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(512, 1) void ws_bwd_dbias_kernel(WsArgs p) {
 
   half4_t* bias_l = (half4_t*)(smem + (size_t)a.n * 128 + 8192);   // [2][T][4][64] half4, accumulator layout as the forward
   if (HAS_BIAS)
-    for (int id = tid; id < 2 * T * 256; id += 512) {
+    for (int id = tid; id < 2 * T * 256; id += NT) {
       const int l = id & 63, j = (id >> 6) & 3, bt = id >> 8, t = bt % T, bb = bt / T;
       half4_t hv = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
       if (2 * pair + bb < T) {
@@ -472,26 +473,26 @@ __global__ __launch_bounds__(512, 1) void ws_bwd_dbias_kernel(WsArgs p) {
     const bf16_t* vb = a.v + seq * vseq + head * 32;
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
-      const int id = tid + 512 * i;
+      const int id = tid + NT * i;
       if (id < npk) {
         kst[i] = *(const u32x4*)(kb + (uint32_t)((id >> 2) * a.ldk + (id & 3) * 8));
         vst[i] = *(const u32x4*)(vb + (uint32_t)((id >> 2) * a.ldv + (id & 3) * 8));
       }
     }
-    qdst = qd_which ? *(const u32x4*)(a.dO + seq * doseq + qd_src) : *(const u32x4*)(a.q + seq * qseq + qd_src);
+    if (NT == 512 || tid < 512) qdst = qd_which ? *(const u32x4*)(a.dO + seq * doseq + qd_src) : *(const u32x4*)(a.q + seq * qseq + qd_src);
     nlse2_n = -a.lse[seq * statseq + stat0] * kLog2e;
     delta_n = a.delta[seq * statseq + stat0];
   };
   auto st_staged = [&]() {
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
-      const int id = tid + 512 * i;
+      const int id = tid + NT * i;
       if (id < npk) {
         *(u32x4*)(kimg + img_off<32>(id >> 2, id & 3)) = kst[i];
         *(u32x4*)(vimg + img_off<32>(id >> 2, id & 3)) = vst[i];
       }
     }
-    *(u32x4*)(qd + qd_dst) = qdst;
+    if (NT == 512 || tid < 512) *(u32x4*)(qd + qd_dst) = qdst;
     nlse2 = nlse2_n;
     delta = delta_n;
   };
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(512, 1) void ws_bwd_dbias_kernel(WsArgs p) {
     if (own) {
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
-        const int t = g + 4 * j;
+        const int t = g + G * j;
         if (t < T) {
           f32x16 S, dP;
           if (HAS_BIAS) {
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(512, 1) void ws_bwd_dbias_kernel(WsArgs p) {
     if (own)
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
-        const int t = g + 4 * j;
+        const int t = g + G * j;
         if (t < T)
 #pragma unroll
           for (int i = 0; i < 16; ++i)
@@ -551,13 +552,13 @@ __global__ __launch_bounds__(512, 1) void ws_bwd_dbias_kernel(WsArgs p) {
       }
   } else {
     float* table = (float*)smem;
-    for (int i = tid; i < a.table_size; i += 512) table[i] = 0.f;
+    for (int i = tid; i < a.table_size; i += NT) table[i] = 0.f;
     __syncthreads();
     if (own) {
       const int yq = a.grid_w > 0 ? q / a.grid_w : 0, xq = a.grid_w > 0 ? q % a.grid_w : 0;
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
-        const int t = g + 4 * j;
+        const int t = g + G * j;
         if (t < T)
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(512, 1) void ws_bwd_dbias_kernel(WsArgs p) {
       }
     }
     __syncthreads();
-    for (int i = tid; i < a.table_size; i += 512) {
+    for (int i = tid; i < a.table_size; i += NT) {
       const float v = table[i];
       if (v != 0.f) atomicAdd(a.dbias_table + (long)head * a.table_size + i, v);
     }
@@ -765,12 +766,13 @@ int ws_bwd_launch(const AttnArgs& a, hipStream_t st) {
              : ws_launch(ws_bwd_dq_kernel<false, QB, NW, ROWLD>, p1, nb1, NW, lds1, st);
   if (e) return e;
   if (db) {
-    const int tpw = (p3.T + 3) / 4;
-    if (hb) {
-      e = tpw <= 3 ? ws_launch(ws_bwd_dbias_kernel<true, 3, 5>, p3, nb3, 8, lds3, st)
-                   : ws_launch(ws_bwd_dbias_kernel<true, 5, 5>, p3, nb3, 8, lds3, st);
+    // 12 waves (three per SIMD, three key tiles each) up to 18 tiles; 8 waves with five tiles each beyond
+    if (p3.T <= 18) {
+      e = hb ? ws_launch(ws_bwd_dbias_kernel<true, 3, 3, 12>, p3, nb3, 12, lds3, st)
+             : ws_launch(ws_bwd_dbias_kernel<false, 3, 3, 12>, p3, nb3, 12, lds3, st);
     } else {
-      e = ws_launch(ws_bwd_dbias_kernel<false, 5, 5>, p3, nb3, 8, lds3, st);
+      e = hb ? ws_launch(ws_bwd_dbias_kernel<true, 5, 5, 8>, p3, nb3, 8, lds3, st)
+             : ws_launch(ws_bwd_dbias_kernel<false, 5, 5, 8>, p3, nb3, 8, lds3, st);
     }
     if (e) return e;
   }
