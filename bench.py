@@ -12,7 +12,7 @@ encoder (12x768, the shape of CXR-BERT), 480x480x240 bf16 volumes, 128-token rep
 Rank 0 prints ONE json line (see README / DESIGN.md "Measurement").
 """
 import argparse
-import json
+import json, re
 import os
 import sys
 import time
@@ -64,23 +64,32 @@ def pmc_traffic(args):
     if args.small or args.batch != 64 or not paths:
         return {"traffic": None}, {}
     path = paths[-1]
-    launches = total = 0.0
+    launches = total = everything = 0.0
     per = {}
+    steps_profiled = None
     for line in open(path):
+        if line.startswith("#"):
+            m = re.search(r"--steps (\d+) --warmup (\d+)", line)
+            if m:                                  # + the two untimed single-stream steps every run appends
+                steps_profiled = int(m.group(1)) + int(m.group(2)) + 2
+            continue
         f = line.rsplit(",", 4)
-        if len(f) != 5 or f[0].startswith(("#", "kernel")):
+        if len(f) != 5 or f[0].startswith("kernel"):
             continue
         name = f[0].split("::")[-1]
         try:
             per[name] = float(f[4]) * 1e6
         except ValueError:
             continue
+        everything += float(f[1]) * float(f[4]) * 1e6
         if name.startswith(("gemm3_kernel", "gemm4_kernel", "gemm2_kernel", "gemm_bf16_kernel")):
             launches += float(f[1])
             total += float(f[1]) * float(f[4]) * 1e6
     rel = os.path.relpath(path, ROOT)
     fam = {"traffic": (total / launches) if launches else None, "traffic_unit": "bytes per launch (mean over the family)",
            "traffic_source": f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+    if steps_profiled:
+        per["__step_total__"] = everything / steps_profiled
     return fam, per
 
 
@@ -398,8 +407,9 @@ def main():
             for ms, w in timed2.get(n, {}).get("items", []):
                 d = tags.setdefault(w["tag"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
                 d["ms"] += ms; d["flops"] += w.get("flops", 0.0); d["bytes"] += w["bytes"]; d["launches"] += 1
-        pmc_names = {"patch_embed_fwd": "patch_ln_fwd_fast", "patch_embed_bwd": "patch_ln_bwd_fast",
-                     "spatial_attention_fwd": "sp_fwd_kernel", "vq_search": "vq_topk3_kernel"}
+        pmc_names = {"patch_embed_fwd": ("patch_ln_fwd_fast",), "patch_embed_bwd": ("patch_ln_bwd_fast",),
+                     "spatial_attention_fwd": ("ws_fwd_kernel",), "vq_search": ("vq_topk3_kernel",),
+                     "spatial_attention_bwd": ("ws_bwd_dq_kernel", "ws_bwd_dbias_kernel", "ws_bwd_dkv_kernel")}
         for tag, d in tags.items():
             if d["ms"] <= 0:
                 continue
@@ -412,10 +422,18 @@ def main():
                 tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 ent.update(bound="mfma", achieved=tf, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_BF16_TFLOPS,
                            frac_of_measured_mfma=tf / peaks["mfma_bf16_tflops"], algorithmic_bytes_per_launch=d["bytes"] / d["launches"])
-            pref = pmc_names.get(tag)
-            hit = [v for k, v in per_kernel_traffic.items() if pref and k.startswith(pref)]
-            ent["traffic"] = hit[0] if hit else None
+            hits = [[v for k, v in per_kernel_traffic.items() if k.startswith(pref)] for pref in pmc_names.get(tag, ())]
+            ent["traffic"] = sum(h[0] for h in hits) if hits and all(hits) else None      # a call = one launch of each kernel named
             kernels[tag] = ent
+        # the whole step against HBM: counter traffic of every kernel of one step (same committed PMC passes) / the copy rate this
+        # box sustains -- the step moves ~1.1 TB, so this, not the MFMA peak, is the bound the step as a whole runs against
+        step_hbm = None
+        if per_kernel_traffic.get("__step_total__") and world == 1:
+            sb = per_kernel_traffic["__step_total__"]
+            ms_copy = sb / (peaks["hbm_copy_gbps"] * 1e9) * 1e3
+            step_hbm = {"bytes_per_step": sb, "ms_at_8_TBps": sb / (PEAK_HBM_GBPS * 1e9) * 1e3, "ms_at_measured_copy_rate": ms_copy,
+                        "frac_of_measured_copy_bound": ms_copy / statistics.median(step_ms),
+                        "what": "sum over all kernels of launches x (2 x FETCH_SIZE + WRITE_SIZE) per step; bound = that / measured float4 copy rate"}
         out = {
             "metric": "CT-volume-report pairs/sec (480x480x240 bf16)", "value": pairs / dt, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -447,6 +465,7 @@ def main():
                              "frac_of_bound": alone["bound_ms"] / alone["total_ms"] if alone["total_ms"] else None,
                              "share_of_time_in_hbm_bound_launches": alone["ms_in_hbm_bound_launches"] / alone["total_ms"] if alone["total_ms"] else None},
                          "measured_peaks": peaks,
+                         "step_hbm": step_hbm,
                          "frac_of_measured_mfma": gemm_tflops / peaks["mfma_bf16_tflops"],
                          "frac_of_measured_mfma_without_stream_overlap": alone_tflops / peaks["mfma_bf16_tflops"],
                          "kernels": kernels,
