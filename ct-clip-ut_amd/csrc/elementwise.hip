@@ -295,3 +295,79 @@ int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* 
   CTCLIP_CHECK_LAUNCH();
 }
 }
+
+// ---- dropout of the text encoder (transformers BertSelfAttention / BertSelfOutput / BertOutput in train mode) ----
+// Keep flags are a pure function of (seed, element index): a counter-based generator (Widynski's "squares", four rounds of
+// square-and-rotate on a 64-bit counter x key) gives every element its own 32-bit draw, keep <=> draw >= p 2^32.  Nothing
+// is stored for the hidden-state dropouts: forward and backward evaluate the same function.
+namespace {
+__device__ __forceinline__ uint32_t draw32(uint64_t ctr, uint64_t key) {
+  uint64_t x = ctr * key, y = x, z = y + key;
+  x = x * x + y; x = (x >> 32) | (x << 32);
+  x = x * x + z; x = (x >> 32) | (x << 32);
+  x = x * x + y; x = (x >> 32) | (x << 32);
+  return (uint32_t)((x * x + z) >> 32);
+}
+// splitmix64 of the caller's seed, forced odd with mixed upper bits: the multiplier key of the generator
+inline uint64_t key_of(uint64_t seed) {
+  uint64_t z = seed + 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return z | 0x0100000000000001ull;
+}
+inline uint32_t threshold_of(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+}
+
+__global__ __launch_bounds__(256) void dropout_keep_kernel(uint8_t* __restrict__ keep, long n, uint32_t thr, uint64_t key,
+                                                           uint64_t off) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    keep[i] = draw32(off + (uint64_t)i, key) >= thr ? 1 : 0;
+}
+// out = x + keep * branch / (1 - p)
+__global__ __launch_bounds__(256) void dropout_add_kernel(const float* __restrict__ x, const float* __restrict__ br,
+                                                          float* __restrict__ out, long n, uint32_t thr, float inv_keep,
+                                                          uint64_t key, uint64_t off) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float b = draw32(off + (uint64_t)i, key) >= thr ? br[i] * inv_keep : 0.f;
+    out[i] = x[i] + b;
+  }
+}
+// d = g * keep / (1 - p), with an optional bf16 mirror
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ g, float* __restrict__ d,
+                                                          bf16_t* __restrict__ d16, long n, uint32_t thr, float inv_keep,
+                                                          uint64_t key, uint64_t off) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = draw32(off + (uint64_t)i, key) >= thr ? g[i] * inv_keep : 0.f;
+    if (d) d[i] = v;
+    if (d16) d16[i] = f32_to_bf16(v);
+  }
+}
+}  // namespace
+
+extern "C" {
+int ctclip_dropout_keep(uint8_t* keep, long n, float p, long seed, long offset, void* stream) {
+  if (n <= 0) return 0;
+  if (!(p >= 0.f && p < 1.f)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(dropout_keep_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, keep, n, threshold_of(p),
+                     key_of((uint64_t)seed), (uint64_t)offset);
+  CTCLIP_CHECK_LAUNCH();
+}
+int ctclip_dropout_add(const float* x, const float* branch, float* out, long n, float p, long seed, long offset,
+                       void* stream) {
+  if (n <= 0) return 0;
+  if (!(p >= 0.f && p < 1.f)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(dropout_add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, branch, out, n,
+                     threshold_of(p), 1.0f / (1.0f - p), key_of((uint64_t)seed), (uint64_t)offset);
+  CTCLIP_CHECK_LAUNCH();
+}
+int ctclip_dropout_bwd(const float* g, float* d, void* d_bf16, long n, float p, long seed, long offset, void* stream) {
+  if (n <= 0) return 0;
+  if (!(p >= 0.f && p < 1.f)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, d, (bf16_t*)d_bf16, n,
+                     threshold_of(p), 1.0f / (1.0f - p), key_of((uint64_t)seed), (uint64_t)offset);
+  CTCLIP_CHECK_LAUNCH();
+}
+}

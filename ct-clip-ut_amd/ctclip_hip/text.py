@@ -8,8 +8,9 @@ with the padding mask (d_head 64), post-LN residual blocks, erf-GELU MLP.
 Absolute position embeddings, post-LayerNorm, erf GELU (BertConfig defaults, and CXR-BERT's).  In train mode the
 config's dropouts apply where transformers applies them: after the embedding LayerNorm, on the attention probabilities
 (keep flags drawn here, applied inside the attention kernels: ctclip_attn_fwd_dropout / _bwd_dropout) and on the two dense
-outputs before their residual adds.  The random stream is torch's generator on the device, not a replay of the
-reference's: parity with dropout on is statistical, the p = 0 path is what the golden vectors pin.
+outputs before their residual adds (ctclip_dropout_add / _bwd: flags re-evaluated from a counter-based generator, nothing
+stored).  The random stream is the library's, seeded per forward from torch's generator, not a replay of the reference's:
+parity with dropout on is statistical, the p = 0 path is what the golden vectors pin.
 """
 from __future__ import annotations
 
@@ -65,18 +66,30 @@ class BertEmbedFn(Function):
         return None, None, r(dword, k3), r(dpos, k4), r(dtype_, k5), r(dlw, k1), r(dlb, k2), None
 
 
-def _dropped(g32, g16, keep, p_drop):
-    """Gradient of the dense branch behind a hidden-state dropout: (f32, bf16) of g * keep / (1 - p); the inputs pass
-    through when there was no dropout."""
-    if keep is None:
+_SITE_SHIFT = 40       # element counters of one dropout site stay below 2^40; (layer, site) selects the offset above it
+
+
+def _site_offset(layer_idx, site):
+    """offset of dropout site `site` (0 attention probabilities, 1 attention-output dense, 2 FFN-output dense) of encoder
+    layer `layer_idx` in the counter space of ctclip_dropout_*"""
+    return (layer_idx * 4 + site) << _SITE_SHIFT
+
+
+def _dropped(g32, g16, drop, site):
+    """Gradient of the dense branch behind a hidden-state dropout: (f32, bf16) of g * keep / (1 - p), the keep flags
+    re-evaluated from (seed, offset); the inputs pass through when there was no dropout."""
+    p_hid, seed, layer_idx = drop[1], drop[3], drop[4]
+    if p_hid <= 0:
         return g32, g16
-    d = g32 * keep.to(F32) * (1.0 / (1.0 - p_drop))
-    return d, d.to(BF16)
+    d = torch.empty_like(g32)
+    d16 = torch.empty_like(g16)
+    hip.dropout_bwd(g32, d, d16, g32.numel(), p_hid, seed, _site_offset(layer_idx, site))
+    return d, d16
 
 
 def _attn_bwd(ctx_drop, *args):
     """hip.attn_bwd, or its dropout form with the forward's keep flags spliced in after `mask`."""
-    keep_a, p_att = ctx_drop[0], ctx_drop[4]
+    keep_a, p_att = ctx_drop[0], ctx_drop[2]
     if keep_a is None:
         return hip.attn_bwd(*args)
     return hip.attn_bwd_dropout(*args[:12], keep_a, 1.0 / (1.0 - p_att), *args[12:])
@@ -89,6 +102,7 @@ class BertLayerFn(Function):
     def forward(ctx, x, mask_add, sh, cfg, *p):
         B, L, heads, dh, dp, eps = cfg[:6]
         p_hid, p_att = (cfg[6], cfg[7]) if len(cfg) > 6 else (0.0, 0.0)      # training-mode dropout (0 = none)
+        seed, layer_idx = (cfg[8], cfg[9]) if len(cfg) > 8 else (0, 0)       # the step's seed, this layer's counter range
         M, Hd = x.shape
         inner = heads * dp
         I = sh["inter"]
@@ -99,20 +113,22 @@ class BertLayerFn(Function):
         lse = torch.empty(B, heads, L, dtype=F32, device=dev)
         scale = 1.0 / math.sqrt(dh)
         # BertSelfAttention drops attention probabilities, BertSelfOutput / BertOutput drop the dense output before the
-        # residual add (transformers modeling_bert.py).  The keep flags are drawn here (torch's generator) and handed to
-        # the kernels / applied element-wise; the p = 0 path below is untouched by any of it.
-        keep_a = keep1 = keep2 = None
+        # residual add (transformers modeling_bert.py).  Keep flags are a function of (seed, layer, site, element)
+        # evaluated inside the kernels (ctclip_dropout_*); only the attention flags are materialised, for the attention
+        # kernels.  The p = 0 path below is untouched by any of it.
+        keep_a = None
         if p_att > 0:
-            keep_a = (torch.rand(B, heads, L, L, device=dev) >= p_att).to(torch.uint8)
+            keep_a = torch.empty(B, heads, L, L, dtype=torch.uint8, device=dev)
+            hip.dropout_keep(keep_a, keep_a.numel(), p_att, seed, _site_offset(layer_idx, 0))
             hip.attn_fwd_dropout(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, lse, None, mask_add, keep_a, 1.0 / (1.0 - p_att),
                                  B, L, heads, dp, 3 * inner, 3 * inner, 3 * inner, inner, scale)
         else:
             hip.attn_fwd(qkv, qkv[:, inner:], qkv[:, 2 * inner:], o, lse, None, mask_add, B, L, heads, dp,
                          3 * inner, 3 * inner, 3 * inner, inner, scale)
         if p_hid > 0:
-            keep1 = torch.rand(M, Hd, device=dev) >= p_hid
             ad = ops.gemm(o, sh["wao"], M, Hd, inner, out_dtype=F32, bias=p[7].detach())
-            a = torch.addcmul(x, ad, keep1.to(F32), value=1.0 / (1.0 - p_hid))
+            a = torch.empty_like(ad)
+            hip.dropout_add(ops._c(x), ad, a, a.numel(), p_hid, seed, _site_offset(layer_idx, 1))
         else:
             a = ops.gemm(o, sh["wao"], M, Hd, inner, out_dtype=F32, bias=p[7].detach(), resid=x)
         x1_16, x1, mean1, rstd1 = ops.layernorm(a, p[8].detach(), p[9].detach(), eps, want16=True, want32=True)
@@ -120,16 +136,16 @@ class BertLayerFn(Function):
         m = torch.empty_like(hpre)
         hip.gelu_fwd(hpre, m, hpre.numel())
         if p_hid > 0:
-            keep2 = torch.rand(M, Hd, device=dev) >= p_hid
             od = ops.gemm(m, sh["wo"], M, Hd, I, out_dtype=F32, bias=p[13].detach())
-            o2 = torch.addcmul(x1, od, keep2.to(F32), value=1.0 / (1.0 - p_hid))
+            o2 = torch.empty_like(od)
+            hip.dropout_add(x1, od, o2, o2.numel(), p_hid, seed, _site_offset(layer_idx, 2))
         else:
             o2 = ops.gemm(m, sh["wo"], M, Hd, I, out_dtype=F32, bias=p[13].detach(), resid=x1)
         _, x2, mean2, rstd2 = ops.layernorm(o2, p[14].detach(), p[15].detach(), eps, want16=False, want32=True)
         ctx.save_for_backward(xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, p[8], p[14],
                               mask_add if mask_add is not None else x.new_empty(0))
         ctx.sh, ctx.cfg, ctx.params = sh, cfg, p
-        ctx.drop = (keep_a, keep1, keep2, p_hid, p_att)
+        ctx.drop = (keep_a, p_hid, p_att, seed, layer_idx)
         return x2
 
     @staticmethod
@@ -138,7 +154,7 @@ class BertLayerFn(Function):
         xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, l1w, l2w, mask_add = ctx.saved_tensors
         sh = ctx.sh
         B, L, heads, dh, dp, eps = ctx.cfg[:6]
-        keep_a, keep1, keep2, p_hid, p_att = ctx.drop
+        keep_a, p_hid, p_att = ctx.drop[:3]
         M, Hd = a.shape
         inner, I = heads * dp, sh["inter"]
         dev = dy.device
@@ -153,7 +169,7 @@ class BertLayerFn(Function):
         do2 = torch.empty(M, Hd, dtype=F32, device=dev)
         do2b = torch.empty(M, Hd, dtype=BF16, device=dev)
         hip.layernorm_bwd(ops._c(dy), o2, l2w, mean2, rstd2, None, do2, do2b, g[14], g[15], M, Hd)
-        dod, do2b = _dropped(do2, do2b, keep2, p_hid)          # into the dense branch; the residual keeps do2 itself
+        dod, do2b = _dropped(do2, do2b, ctx.drop, 2)          # into the dense branch; the residual keeps do2 itself
         ops.colsum(dod, out=g[13])
         dm = ops.dgrad(do2b, sh["wo"], M, Hd, I, out_dtype=BF16, wT16=sh.get("woT"))
         ops.wgrad(do2b, m, Hd, I, M, out=g[12])
@@ -166,7 +182,7 @@ class BertLayerFn(Function):
         da = torch.empty(M, Hd, dtype=F32, device=dev)
         dab = torch.empty(M, Hd, dtype=BF16, device=dev)
         hip.layernorm_bwd(dx1, a, l1w, mean1, rstd1, None, da, dab, g[8], g[9], M, Hd)
-        dad, dab = _dropped(da, dab, keep1, p_hid)
+        dad, dab = _dropped(da, dab, ctx.drop, 1)
         ops.colsum(dad, out=g[7])
         do = ops.dgrad(dab, sh["wao"], M, Hd, inner, out_dtype=BF16, wT16=sh.get("waoT"))
         ops.wgrad(dab, o, Hd, inner, M, out=g[6])
@@ -189,7 +205,7 @@ class BertLayerFn(Function):
         xb, qkv, o, lse, a, mean1, rstd1, x1_16, hpre, m, o2, mean2, rstd2, l1w, l2w, mask_add = ctx.saved_tensors
         sh = ctx.sh
         B, L, heads, dh, dp, eps = ctx.cfg[:6]
-        keep_a, keep1, keep2, p_hid, p_att = ctx.drop
+        keep_a, p_hid, p_att = ctx.drop[:3]
         M, Hd = a.shape
         inner, I = heads * dp, sh["inter"]
         dev = dy.device
@@ -201,7 +217,7 @@ class BertLayerFn(Function):
         do2b = torch.empty(M, Hd, dtype=BF16, device=dev)
         dl2w, dl2b = z(Hd), z(Hd)
         hip.layernorm_bwd(ops._c(dy), o2, l2w, mean2, rstd2, None, do2, do2b, dl2w, dl2b, M, Hd)
-        dod, do2b = _dropped(do2, do2b, keep2, p_hid)
+        dod, do2b = _dropped(do2, do2b, ctx.drop, 2)
         dbo = ops.colsum(dod)
         dm = ops.dgrad(do2b, sh["wo"], M, Hd, I, out_dtype=BF16, wT16=sh.get("woT"))
         dwo = ops.wgrad(do2b, m, Hd, I, M)
@@ -215,7 +231,7 @@ class BertLayerFn(Function):
         dab = torch.empty(M, Hd, dtype=BF16, device=dev)
         dl1w, dl1b = z(Hd), z(Hd)
         hip.layernorm_bwd(dx1, a, l1w, mean1, rstd1, None, da, dab, dl1w, dl1b, M, Hd)
-        dad, dab = _dropped(da, dab, keep1, p_hid)
+        dad, dab = _dropped(da, dab, ctx.drop, 1)
         dbao = ops.colsum(dad)
         do = ops.dgrad(dab, sh["wao"], M, Hd, inner, out_dtype=BF16, wT16=sh.get("waoT"))
         dwao = ops.wgrad(dab, o, Hd, inner, M)
@@ -293,7 +309,10 @@ def bert_last_hidden_state(model, input_ids, token_type_ids=None, attention_mask
     mask_add = None
     if attention_mask is not None:
         mask_add = ((1.0 - attention_mask.to(F32)) * torch.finfo(F32).min).contiguous()
-    lcfg = (B, L, heads, dh, dp, float(cfg.layer_norm_eps), p_hid, p_att)
-    for layer in model.encoder.layer:
+    # one seed per forward from torch's (CPU) default generator -- torch.manual_seed() makes a run reproducible, no device
+    # sync -- and a counter range per (layer, site): see ctclip_dropout_* in include/ctclip_hip.h
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p_hid > 0 or p_att > 0) else 0
+    for li, layer in enumerate(model.encoder.layer):
+        lcfg = (B, L, heads, dh, dp, float(cfg.layer_norm_eps), p_hid, p_att, seed, li)
         x = BertLayerFn.apply(x, mask_add, _layer_shadows(layer, heads, dh, dp), lcfg, *_layer_params(layer))
     return x.reshape(B, L, Hd)

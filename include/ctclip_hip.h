@@ -202,6 +202,18 @@ int ctclip_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16,
                      float beta2, float eps, float weight_decay, int decoupled, float bias_corr1, float bias_corr2,
                      const float* gnorm_sq, float max_norm, void* stream);
 
+/* ---- dropout of the text encoder in train mode (transformers modeling_bert.py: BertSelfAttention drops attention
+ * probabilities, BertSelfOutput / BertOutput drop the dense output before the residual add; models/ctclip.py:107 calls the
+ * encoder under model.train()).  keep(i) is a pure function of (seed, offset + i) -- a counter-based generator, one 32-bit
+ * draw per element, keep <=> draw >= p 2^32 -- so the hidden-state dropouts store nothing: forward and backward evaluate
+ * the same function.  The random stream is therefore this library's, seeded by the caller (text.py draws the seed from
+ * torch's generator); it is not a replay of the reference's CUDA Philox stream. */
+int ctclip_dropout_keep(uint8_t* keep, long n, float p, long seed, long offset, void* stream);      /* flags for ctclip_attn_*_dropout */
+int ctclip_dropout_add(const float* x, const float* branch, float* out, long n, float p, long seed, long offset,
+                       void* stream);                                                             /* out = x + keep branch / (1-p) */
+int ctclip_dropout_bwd(const float* g, float* d, void* d_bf16, long n, float p, long seed, long offset,
+                       void* stream);                                                             /* d = keep g / (1-p), f32 and/or bf16 */
+
 /* ---- BERT embeddings (transformers BertEmbeddings): word[ids] + pos[0..L) + type[token_type] ---- */
 int ctclip_bert_embed_fwd(const long* ids, const long* token_type, const float* word, const float* pos, const float* type,
                           float* out, long rows, int L, int hidden, void* stream);

@@ -174,9 +174,8 @@ def test_bert_golden():
 
 def test_bert_layer_with_dropout_vs_torch_same_flags():
     """One encoder layer in train mode with the config's dropouts (transformers BertSelfAttention / BertSelfOutput /
-    BertOutput) against plain torch f32 math that draws the same keep flags: re-seeding torch's device generator before
-    each run makes the torch.rand calls of ctclip_hip.text.BertLayerFn reproducible, in its order (attention flags, then
-    the two hidden-state flags)."""
+    BertOutput) against plain torch f32 math with the same keep flags: the flags are the library's counter-based draws for
+    (seed, layer, site), materialised here through ctclip_dropout_keep; the layer itself re-evaluates them in its kernels."""
     from transformers import BertConfig, BertModel
     from ctclip_hip.text import BertLayerFn, _layer_params, _layer_shadows
     torch.manual_seed(3)
@@ -192,11 +191,21 @@ def test_bert_layer_with_dropout_vs_torch_same_flags():
     dy = torch.randn(B * L, Hd, device=DEV)
     P = _layer_params(layer)
 
-    # reference with the same flags
-    torch.manual_seed(77)
-    keep_a = (torch.rand(B, heads, L, L, device=DEV) >= p_att).float() / (1 - p_att)
-    keep1 = (torch.rand(B * L, Hd, device=DEV) >= p_hid).float() / (1 - p_hid)
-    keep2 = (torch.rand(B * L, Hd, device=DEV) >= p_hid).float() / (1 - p_hid)
+    # reference with the same flags: the library's counter-based draws for (seed, layer 5, site) -- ctclip_dropout_keep
+    from ctclip_hip.lib import hip
+    from ctclip_hip.text import _site_offset
+    seed, layer_idx = 123456789012345, 5
+    def flags(shape, p, site):
+        k = torch.empty(*shape, dtype=torch.uint8, device=DEV)
+        hip.dropout_keep(k, k.numel(), p, seed, _site_offset(layer_idx, site))
+        return k
+    ka, k1, k2 = flags((B, heads, L, L), p_att, 0), flags((B * L, Hd), p_hid, 1), flags((B * L, Hd), p_hid, 2)
+    for k, pdrop in ((ka, p_att), (k1, p_hid), (k2, p_hid)):          # the draws are fair and the sites differ
+        assert abs(float(k.float().mean()) - (1 - pdrop)) < 4 * math.sqrt(pdrop * (1 - pdrop) / k.numel()) + 1e-3
+    assert not torch.equal(k1, k2)
+    again = flags((B * L, Hd), p_hid, 1)
+    assert torch.equal(again, k1)
+    keep_a, keep1, keep2 = ka.float() / (1 - p_att), k1.float() / (1 - p_hid), k2.float() / (1 - p_hid)
     xr = x0.clone().requires_grad_(True)
     lin = torch.nn.functional.linear
     split = lambda t: t.reshape(B, L, heads, dh).permute(0, 2, 1, 3)
@@ -211,9 +220,8 @@ def test_bert_layer_with_dropout_vs_torch_same_flags():
     for t in P:
         t.grad = None
 
-    torch.manual_seed(77)
     xh = x0.clone().requires_grad_(True)
-    lcfg = (B, L, heads, dh, ops_head_pad(dh), float(cfg.layer_norm_eps), p_hid, p_att)
+    lcfg = (B, L, heads, dh, ops_head_pad(dh), float(cfg.layer_norm_eps), p_hid, p_att, seed, layer_idx)
     out = BertLayerFn.apply(xh, mask_add, _layer_shadows(layer, heads, dh, ops_head_pad(dh)), lcfg, *P)
     out.backward(dy)
     torch.cuda.synchronize()
@@ -231,8 +239,14 @@ def test_bert_layer_with_dropout_vs_torch_same_flags():
     e2 = bert_last_hidden_state(m, ids)
     assert torch.equal(e1, e2)
     m.train()
+    torch.manual_seed(11)
     t1 = bert_last_hidden_state(m, ids)
     assert not torch.equal(t1, e1) and bool(torch.isfinite(t1).all())
+    t2 = bert_last_hidden_state(m, ids)                       # a new seed per forward
+    assert not torch.equal(t2, t1)
+    torch.manual_seed(11)
+    t3 = bert_last_hidden_state(m, ids)                       # torch.manual_seed makes it reproducible
+    assert torch.equal(t3, t1)
 
 
 def ops_head_pad(dh):

@@ -96,12 +96,18 @@ def test_rccl_branches_run_at_world_size_one():
         for a, b in zip(losses, losses2):
             print(f"  loss single-process {a:.7f}  through RCCL {b:.7f}")
             assert abs(a - b) <= 1e-3 * abs(a)                          # f32 atomics reorder sums, nothing else differs
-        worst = 0.0
+        # Both runs execute the same kernels; what differs is the order of f32 atomic adds inside gradient sums.  Adam's
+        # first steps move every element by ~lr * sign(g), so an element whose gradient is rounding noise may move the
+        # other way: allowed per element is that (2 steps x 2 lr) or 1e-3 of the tensor's peak, whichever is larger.
+        lr, worst, worst_name = 1.25e-5, 0.0, ""
         for k, v in clip2.state_dict().items():
             if v.is_floating_point() and v.numel():
-                worst = max(worst, float((v - ref_state[k]).abs().max() / (ref_state[k].abs().max() + 1e-12)))
-        print(f"  worst parameter deviation after two steps: {worst:.2e}")
-        assert worst <= 1e-3
+                dev = float((v - ref_state[k]).abs().max())
+                allowed = max(4.0 * lr, 1e-3 * float(ref_state[k].abs().max()))
+                if dev / allowed > worst:
+                    worst, worst_name = dev / allowed, f"{k}: {dev:.2e} (peak {float(ref_state[k].abs().max()):.2e})"
+        print(f"  worst parameter deviation after two steps, in units of the allowance: {worst:.2f}  [{worst_name}]")
+        assert worst <= 1.0
         sync.close()
     finally:
         dist.destroy_process_group()
