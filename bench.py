@@ -469,9 +469,10 @@ def main():
                          "frac_of_measured_mfma": gemm_tflops / peaks["mfma_bf16_tflops"],
                          "frac_of_measured_mfma_without_stream_overlap": alone_tflops / peaks["mfma_bf16_tflops"],
                          "kernels": kernels,
-                         "note": "achieved: HIP-event durations inside the timed region, where weight-gradient GEMMs run "
-                                 "concurrently on a second stream; *_without_stream_overlap and `kernels`: same launches, two extra "
-                                 "untimed steps on one stream; flops counted on the unpadded GEGLU width 1365"},
+                         "side_stream": bool(side_was),
+                         "note": "achieved: HIP-event durations inside the timed region (single stream unless CTCLIP_WGRAD_STREAM=1 "
+                                 "puts the weight-gradient GEMMs on a second one); *_without_stream_overlap and `kernels`: same "
+                                 "launches, two extra untimed steps on one stream; flops counted on the unpadded GEGLU width 1365"},
         }
         if not args.no_cpu_baseline and world == 1 and not args.small:
             out["cpu_baseline"] = cpu_baseline(model, depth, size, args.text_len, text_cfg["vocab_size"])

@@ -101,16 +101,17 @@ def _splits_for(m_out: int, n_out: int, k: int) -> int:
     return max(1, min(nk, (1024 + tiles - 1) // tiles))
 
 
-# ---- weight gradients on a second HIP stream -------------------------------------------------------------------------
-# Weight-gradient GEMMs are off the backward's critical path (their results only land in `.grad`) and are matrix-pipe
-# bound, while the kernels that follow them on the main stream (GEGLU / LayerNorm / PEG backward) are HBM bound: issued on
-# a side stream the two kinds share the CUs.  The side stream waits for an event recorded at the issue point (inputs are
-# complete), the operands are pinned for it (`record_stream`), and the main stream re-joins it in a callback queued to
-# the end of the running backward pass, so `.grad` is complete whenever `backward()` returns.  CTCLIP_WGRAD_STREAM=0
-# keeps everything on one stream.
+# ---- weight gradients on a second HIP stream (optional, off by default) -----------------------------------------------
+# Weight-gradient GEMMs are off the backward's critical path (their results only land in `.grad`); issued on a side stream
+# they share the CUs with the kernels that follow them on the main stream.  The side stream waits for an event recorded
+# at the issue point (inputs are complete), the operands are pinned for it (`record_stream`), and the main stream re-joins
+# it in a callback queued to the end of the running backward pass, so `.grad` is complete whenever `backward()` returns.
+# Measured on the MI355X (same box, interleaved runs of the full step): 319.2 / 317.4 ms with the side stream, 316.4 /
+# 318.5 ms without -- every kernel of this step fills the chip by itself, so co-scheduling buys nothing and only stretches
+# each launch.  CTCLIP_WGRAD_STREAM=1 turns it on.
 import os as _os
 
-_side = {"on": _os.environ.get("CTCLIP_WGRAD_STREAM", "1") != "0", "stream": None, "dirty": False, "queued": False}
+_side = {"on": _os.environ.get("CTCLIP_WGRAD_STREAM", "0") != "0", "stream": None, "dirty": False, "queued": False}
 
 
 def join_side_stream() -> None:
