@@ -58,6 +58,16 @@ __device__ __forceinline__ void read_frag_tr(uint32_t tile_lds, int cbase, int s
   hi = tr_read_asm(tile_lds + tile_off(klo + 4, c0 >> 3) + sub);
 }
 
+// MFMA 16x16x32 form: element j = T[k = 8*(lane>>4) + j][cbase + (lane&15)] -- the whole 32-deep K-step in one fragment
+__device__ __forceinline__ void read_frag_tr16(uint32_t tile_lds, int cbase, int lane, short4v& lo, short4v& hi) {
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int c0 = cbase + 4 * p;
+  const int klo = 8 * g + q;
+  const uint32_t sub = (uint32_t)((p & 1) * 8);
+  lo = tr_read_asm(tile_lds + tile_off(klo, c0 >> 3) + sub);
+  hi = tr_read_asm(tile_lds + tile_off(klo + 4, c0 >> 3) + sub);
+}
+
 // element offset (from the operand base, at k-tile 0) of the 16 bytes lane `lane` contributes to 1 KiB piece `p`
 // (k-rows 2p, 2p+1) of the tile whose first column is c0; its LDS destination is piece_base + lane*16
 __device__ __forceinline__ long piece_src(int p, int lane, int c0, int R, long ld) {
@@ -71,6 +81,7 @@ __device__ __forceinline__ long piece_src(int p, int lane, int c0, int R, long l
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                          \
                                    (__attribute__((address_space(3))) void*)(uintptr_t)(ldsoff), 16, 0, 0)
 
+template <bool MF16>
 __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -109,23 +120,54 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
     for (int j = j0; j < j0 + PPW / 2; ++j) G4_GLDS(src[j] + (long)t * kstep[j], sb + dst[j]);
   };
 
+  // the same 128 accumulator registers either way: 4 x 2 tiles of 32 x 32 or 8 x 4 tiles of 16 x 16
   f32x16 acc[4][2];
+  f32x4 acc16[MF16 ? 8 : 1][MF16 ? 4 : 1];
+  if (MF16) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc16[MF16 ? i : 0][MF16 ? j : 0][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
 
 #pragma unroll
   for (int t = 0; t < NS - 1; ++t)
     if (t < nk) { issue_part(t, 0); issue_part(t, PPW / 2); }
 
+  // MF16: set s holds A tiles 4 s .. 4 s + 3 and B tiles 2 s, 2 s + 1 (16 wide each); otherwise k-half s of every tile
   auto read_set = [&](short4v (&raw)[12], uint32_t sa_l, int s) {
+    if (MF16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) read_frag_tr(sa_l, wm * 128 + i * 32, s, lane, raw[2 * i], raw[2 * i + 1]);
+      for (int i = 0; i < 4; ++i) read_frag_tr16(sa_l, wm * 128 + (4 * s + i) * 16, lane, raw[2 * i], raw[2 * i + 1]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) read_frag_tr(sa_l + SUB, wn * 64 + j * 32, s, lane, raw[8 + 2 * j], raw[9 + 2 * j]);
+      for (int j = 0; j < 2; ++j) read_frag_tr16(sa_l + SUB, wn * 64 + (2 * s + j) * 16, lane, raw[8 + 2 * j], raw[9 + 2 * j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) read_frag_tr(sa_l, wm * 128 + i * 32, s, lane, raw[2 * i], raw[2 * i + 1]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) read_frag_tr(sa_l + SUB, wn * 64 + j * 32, s, lane, raw[8 + 2 * j], raw[9 + 2 * j]);
+    }
+  };
+  auto mma16_all = [&](short4v (&ra)[12], short4v (&rb)[12]) {
+    bf16x8 fa[8], fb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fa[i] = join_tr(ra[2 * i], ra[2 * i + 1]); fa[4 + i] = join_tr(rb[2 * i], rb[2 * i + 1]); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { fb[j] = join_tr(ra[8 + 2 * j], ra[9 + 2 * j]); fb[2 + j] = join_tr(rb[8 + 2 * j], rb[9 + 2 * j]); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc16[MF16 ? i : 0][MF16 ? j : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc16[MF16 ? i : 0][MF16 ? j : 0], 0, 0, 0);
   };
   auto mma_set = [&](short4v (&raw)[12]) {
     bf16x8 fa[4], fb[2];
@@ -168,8 +210,12 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
   };
   auto mfma_block = [&]() {
     __builtin_amdgcn_s_setprio(1);
-    mma_set(r0);
-    mma_set(r1);
+    if (MF16) {
+      mma16_all(r0, r1);
+    } else {
+      mma_set(r0);
+      mma_set(r1);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   {                                                 // stage 0 has landed for everybody
@@ -207,6 +253,24 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
 
   // split-K: f32 atomics straight from the accumulators.  For a fixed register the 64 lanes cover two 128-byte row
   // segments -- the access shape global_atomic_add_f32 runs at full rate with.
+  if (MF16) {
+    // 16 x 16 tiles: a register covers four 64-byte row segments
+    const int q4 = lane >> 4, ml = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = col0 + wn * 64 + j * 16 + ml;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + wm * 128 + i * 16 + 4 * q4 + r;
+          if (row >= g.M) continue;
+          atomicAdd(g.C + (long)row * g.ldc + col, acc16[MF16 ? i : 0][MF16 ? j : 0][r] * g.alpha);
+        }
+      }
+    return;
+  }
   const int half = lane >> 5, lc = lane & 31;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -242,10 +306,13 @@ int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int
   const size_t lds = (size_t)NS * STAGE;           // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm4_kernel, dim3(g.tiles_m * g.tiles_n * g.split_k), dim3(NT), lds, st, g);
+  static const bool mf32 = CTCLIP_KNOB("CTCLIP_GEMM4_MFMA32") != nullptr;
+  if (mf32) hipLaunchKernelGGL(gemm4_kernel<false>, dim3(g.tiles_m * g.tiles_n * g.split_k), dim3(NT), lds, st, g);
+  else hipLaunchKernelGGL(gemm4_kernel<true>, dim3(g.tiles_m * g.tiles_n * g.split_k), dim3(NT), lds, st, g);
   return (int)hipGetLastError();
 }
