@@ -263,8 +263,13 @@ int ws_fwd_launch(const AttnArgs& a, hipStream_t st) {
 // LDS read wants for dQ^T += K^T dS^T.  One K / V fetch serves the QB query blocks.
 // delta[q] = sum_d dO[q][d] O[q][d] is computed here from the dO fragment the wave holds anyway (and stored for the other
 // passes).
-template <bool HAS_BIAS, int QB, int NW, bool ROWLD>
+// DBL (QB = 1 only): d(bias) in the same pass.  The block's T d(bias) tiles live in LDS as f32 in accumulator layout; a wave
+// adds its dS tile with a plain read-modify-write under a per-tile LDS lock (one lane's compare-and-swap; ds_add_f32 from
+// every lane was measured at ~190 cycles per instruction) and every wave starts its walk over the key tiles somewhere else,
+// so two waves rarely want the same tile at the same time.
+template <bool HAS_BIAS, int QB, int NW, bool ROWLD, bool DBL>
 __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
+  static_assert(!DBL || QB == 1, "the d(bias) tiles of one query block fill the LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const AttnArgs& a = p.a;
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, half = lane >> 5;
@@ -280,8 +285,18 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
   const int q0 = grp * QB * 32;
 
   half4_t* bias_l = (half4_t*)smem;                                // [QB][T][4][64] half4
-  char* kimg = smem + (size_t)(HAS_BIAS ? QB * T : 0) * 2048 + (size_t)w * (ROWLD ? 8192 : 4096);
-  char* vimg = kimg + 4096;                                        // ROWLD only
+  char* after_bias = smem + (size_t)(HAS_BIAS ? QB * T : 0) * 2048;
+  float4* dbias_l = (float4*)after_bias;                           // DBL: [T][4][64] float4 = registers 4 j .. 4 j + 3 of lane
+  unsigned* lock_l = (unsigned*)(after_bias + (size_t)T * 4096);   // DBL: one word per key tile
+  // images: [K 2 KiB | V 2 KiB] per buffer; DBL has room for one buffer per wave only
+  constexpr int IMG_BUFS = DBL ? 1 : 2;
+  constexpr int IMG_WAVE = (ROWLD ? 4096 : 2048) * IMG_BUFS;
+  char* kimg = after_bias + (DBL ? (size_t)T * 4096 + 128 : 0) + (size_t)w * IMG_WAVE;
+  char* vimg = kimg + 2048 * IMG_BUFS;                             // ROWLD only
+  if (DBL) {
+    for (int id = tid; id < T * 256; id += NW * 64) dbias_l[id] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int id = tid; id < T; id += NW * 64) lock_l[id] = 0u;
+  }
   if (HAS_BIAS) {
     for (int id = tid; id < QB * T * 256; id += NW * 64) {
       const int l = id & 63, j = (id >> 6) & 3, bt = id >> 8, t = bt % T, b = bt / T;
@@ -293,8 +308,8 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
       }
       bias_l[id] = hv;
     }
-    __syncthreads();
   }
+  if (HAS_BIAS || DBL) __syncthreads();
 
   // ROWLD: a tile is fetched as 16 whole 64-byte rows per wave-instruction (4 lanes per row) -- half the cache lines per
   // instruction of the fragment pattern (32 rows x 32 bytes) -- and both operands are read back from the LDS image
@@ -310,6 +325,8 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
   const long kseq = (long)a.n * a.ldk, vseq = (long)a.n * a.ldv, qseq = (long)a.n * a.ldq, doseq = (long)a.n * a.lddo,
              oseq = (long)a.n * a.ldo;
   const uint32_t ktile = (uint32_t)(32 * a.ldk), vtile = (uint32_t)(32 * a.ldv);
+  const int rot = DBL ? (w * T) / NW : 0;                          // this wave's first key tile
+  auto phys = [&](int it) { const int t = it + rot; return t >= T ? t - T : t; };
 
   for (int seq = seq0 + w; seq < seq1; seq += NW) {
     const bf16_t* kb = a.k + seq * kseq + koff;
@@ -321,8 +338,8 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
       vr[slot][0] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * vtile));
       vr[slot][1] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * vtile + vstep));
     };
-    request(0, 0);
-    if (T > 1) request(1, 1);
+    request(0, phys(0));
+    if (T > 1) request(1, phys(1));
     bf16x8 qf[QB][2], df[QB][2];
     float nlse2[QB], delta[QB];
     f32x16 dq[QB];
@@ -346,13 +363,15 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
       zero_acc(dq[b]);
     }
 
-    auto tile = [&](int slot, int t) {
-      char* ki = kimg + (t & 1) * 2048;
+    auto tile = [&](int slot, int it) {
+      const int t = phys(it);
+      char* ki = kimg + (IMG_BUFS == 2 ? (it & 1) * 2048 : 0);
       bf16x8 k0 = kr[slot][0], k1 = kr[slot][1], v0 = vr[slot][0], v1 = vr[slot][1];
+      if (IMG_BUFS == 1) asm volatile("" ::: "memory");             // single image: the previous tile's reads stay above
       *(bf16x8*)(ki + kst0) = k0;
       *(bf16x8*)(ki + kst1) = k1;
       if (ROWLD) {
-        char* vi = vimg + (t & 1) * 2048;
+        char* vi = vimg + (IMG_BUFS == 2 ? (it & 1) * 2048 : 0);
         *(bf16x8*)(vi + kst0) = v0;
         *(bf16x8*)(vi + kst1) = v1;
         k0 = row_frag<32>(ki, 0, 0, lane); k1 = row_frag<32>(ki, 0, 1, lane);
@@ -391,7 +410,29 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
         dq[b] = mfma32(kt1, d1, dq[b]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (t + 2 < T) request(slot, t + 2);                         // a whole tile of work ahead of its use
+      if (DBL) {
+        // d(bias) tile t += dS: take the tile's lock (bounded spin: a wave never holds a lock across anything but the
+        // few LDS instructions below), read-modify-write, release.  LDS executes a wave's instructions in order, so the
+        // releasing store is performed after the tile's stores.
+        unsigned* lk = lock_l + t;
+        for (int spins = 0; spins < (1 << 22); ++spins) {
+          unsigned old = 1u;
+          if (lane == 0) old = atomicCAS(lk, 0u, 1u);
+          if (__builtin_amdgcn_readfirstlane(old) == 0u) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        float4* dt = dbias_l + t * 256 + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 v = dt[j * 64];
+          v.x += S[0][4 * j]; v.y += S[0][4 * j + 1]; v.z += S[0][4 * j + 2]; v.w += S[0][4 * j + 3];
+          dt[j * 64] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) *(volatile unsigned*)lk = 0u;
+      }
+      if (it + 2 < T) request(slot, phys(it + 2));                 // a whole tile of work ahead of its use
     };
     int t = 0;
     for (; t + 1 < T; t += 2) {
@@ -405,6 +446,38 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
       if (b >= nqb) continue;
       const f32x16 dd[1] = {dq[b]};
       store_rows<32>(a.dq + ((long)seq * a.n + q0 + 32 * b + r) * a.lddq + head * 32, dd, a.scale, lane);
+    }
+  }
+
+  if (DBL) {
+    __syncthreads();                                               // every wave's tiles are in
+    const float* dl = (const float*)dbias_l;                       // element (t, register i, lane l) at ((t*4 + i/4)*64 + l)*4 + i%4
+    if (a.dbias_dense) {
+      for (int id = tid; id < T * 1024; id += NW * 64) {
+        const int e = id & 3, l = (id >> 2) & 63, j = (id >> 8) & 3, t = id >> 10, i = 4 * j + e;
+        atomicAdd(a.dbias_dense + ((long)head * a.n + q0 + (l & 31)) * a.n + 32 * t + acc_row(i, l >> 5), dl[id]);
+      }
+    } else {
+      float* table = (float*)(after_bias + (size_t)T * 4096 + 128);   // the images are idle now
+      for (int i = tid; i < a.table_size; i += NW * 64) table[i] = 0.f;
+      __syncthreads();
+      for (int id = tid; id < T * 1024; id += NW * 64) {
+        const int e = id & 3, l = (id >> 2) & 63, j = (id >> 8) & 3, t = id >> 10, i = 4 * j + e;
+        const int q = q0 + (l & 31), key = 32 * t + acc_row(i, l >> 5);
+        int ti;
+        if (a.grid_w > 0) {
+          const int yq = q / a.grid_w, xq = q % a.grid_w, yk = key / a.grid_w, xk = key % a.grid_w;
+          ti = (yq - yk + a.grid_h - 1) * (2 * a.grid_w - 1) + (xq - xk + a.grid_w - 1);
+        } else {
+          ti = a.relidx[(long)q * a.n + key];
+        }
+        atomicAdd(&table[ti], dl[id]);
+      }
+      __syncthreads();
+      for (int i = tid; i < a.table_size; i += NW * 64) {
+        const float v = table[i];
+        if (v != 0.f) atomicAdd(a.dbias_table + (long)head * a.table_size + i, v);
+      }
     }
   }
 }
@@ -762,10 +835,31 @@ int ws_bwd_launch(const AttnArgs& a, hipStream_t st) {
     if (table && (size_t)a.table_size * 4 > (size_t)a.n * 128) return -1;
     if (table && a.grid_w <= 0 && !a.relidx) return -1;
   }
-  int e = hb ? ws_launch(ws_bwd_dq_kernel<true, QB, NW, ROWLD>, p1, nb1, NW, lds1, st)
-             : ws_launch(ws_bwd_dq_kernel<false, QB, NW, ROWLD>, p1, nb1, NW, lds1, st);
+  // d(bias) inside the dQ pass (one query block per workgroup, tiles under LDS locks) when it fits; else its own pass
+  int nbf = 0;
+  const WsArgs pf = ws_plan(a, 1, NW, &nbf);
+  const size_t ldsf = (size_t)(hb ? pf.T : 0) * 2048 + (size_t)pf.T * 4096 + 128 + (size_t)NW * (ROWLD ? 4096 : 2048);
+  const bool fused = db && ldsf <= 160 * 1024 && (!table || (size_t)a.table_size * 4 <= (size_t)NW * 2048) &&
+                     !CTCLIP_KNOB("CTCLIP_ATTN_WS_DBIAS_PASS");
+  int e;
+  int nbf12 = 0;
+  const WsArgs pf12 = ws_plan(a, 1, 12, &nbf12);
+  const size_t ldsf12 = ldsf + (size_t)(12 - NW) * (ROWLD ? 4096 : 2048);
+  // 12 waves (the fused kernel needs 156 registers) when their K / V images still fit: 4846 vs 5210 us per backward call
+  const bool w12 = fused && ldsf12 <= 160 * 1024 && (!table || (size_t)a.table_size * 4 <= (size_t)12 * 2048) &&
+                   !CTCLIP_KNOB("CTCLIP_ATTN_WS_FUSED_W8");
+  if (w12) {
+    e = hb ? ws_launch(ws_bwd_dq_kernel<true, 1, 12, ROWLD, true>, pf12, nbf12, 12, ldsf12, st)
+           : ws_launch(ws_bwd_dq_kernel<false, 1, 12, ROWLD, true>, pf12, nbf12, 12, ldsf12, st);
+  } else if (fused) {
+    e = hb ? ws_launch(ws_bwd_dq_kernel<true, 1, NW, ROWLD, true>, pf, nbf, NW, ldsf, st)
+           : ws_launch(ws_bwd_dq_kernel<false, 1, NW, ROWLD, true>, pf, nbf, NW, ldsf, st);
+  } else {
+    e = hb ? ws_launch(ws_bwd_dq_kernel<true, QB, NW, ROWLD, false>, p1, nb1, NW, lds1, st)
+           : ws_launch(ws_bwd_dq_kernel<false, QB, NW, ROWLD, false>, p1, nb1, NW, lds1, st);
+  }
   if (e) return e;
-  if (db) {
+  if (db && !fused) {
     // 12 waves (three per SIMD, three key tiles each) up to 18 tiles; 8 waves with five tiles each beyond
     if (p3.T <= 18) {
       e = hb ? ws_launch(ws_bwd_dbias_kernel<true, 3, 3, 12>, p3, nb3, 12, lds3, st)
