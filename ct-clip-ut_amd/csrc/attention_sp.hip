@@ -708,6 +708,13 @@ int ctclip_attn_sp_bwd(const CtclipAttnArgs& a, int dhead, hipStream_t st) {
   if (table && (size_t)a.table_size * 4 > part_bytes) return -1;
   if (table && a.grid_w <= 0 && !a.relidx) return -1;
   {
+    // both passes must fit the CU's LDS (the dK/dV pass keeps Q and dO images of the whole sequence): decide before
+    // anything is launched, the per-sequence kernels of attention.hip take the shape otherwise
+    const size_t l1 = (size_t)a.n * 64 + 8192 + part_bytes;
+    const size_t l2 = (size_t)2 * a.n * 64 + 8192 + (size_t)2 * a.n * 4 + (size_t)2 * p.W * 4096;
+    if (l1 > 160 * 1024 || l2 > 160 * 1024) return -1;
+  }
+  {
     const long items = (long)a.nseq * a.n * a.heads * 4;
     hipLaunchKernelGGL(sp_delta_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, a.dO, a.oin, a.delta,
                        (long)a.nseq * a.n, a.n, a.heads, a.lddo, a.ldo);

@@ -483,179 +483,6 @@ __global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dq_kernel(WsArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward pass 1b: d(bias)[head][q][key] = sum over sequences of dS.  The sum needs an owner per (query block, key tile):
-// adding the waves' dS into shared LDS tiles with ds_add_f32 was measured at ~190 cycles per wave-instruction (25 ms per
-// call), so here -- and only here -- the waves of a workgroup split the KEY TILES instead of the sequences and keep their
-// tiles' sums in registers across the whole chunk:
-//   workgroup = (head, pair of 32-row query blocks, chunk of sequences), NW = 12 (or 8) waves: wave w owns query block
-//   (w & 1) and key tiles (w >> 1) + (NW / 2) j -- three tiles each at n = 576 with 12 waves.  Per sequence the workgroup stages K, V (whole rows of the head) and the two Q / dO blocks into
-//   swizzled LDS images (prefetched into registers during the previous sequence), two barriers per sequence, no exchange.
-// The bias tiles of both blocks sit in LDS as fp16 in accumulator layout, as in the other passes.  delta comes from pass 1.
-// ------------------------------------------------------------------------------------------------
-template <bool HAS_BIAS, int TPW, int NPK, int NW>
-__global__ __launch_bounds__(NW * 64, 1) void ws_bwd_dbias_kernel(WsArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const AttnArgs& a = p.a;
-  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, half = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int T = p.T;
-  const int G2 = (T + 1) / 2;
-  int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int pair = L % G2;
-  L /= G2;
-  const int chunk_id = L % p.nchunks, head = L / p.nchunks;
-  const int seq0 = chunk_id * p.chunk, seq1 = min(a.nseq, seq0 + p.chunk);
-  constexpr int NT = NW * 64, G = NW / 2;                         // threads; key-tile groups
-  const int b = w & 1, g = w >> 1;
-  const bool own = 2 * pair + b < T;                               // an odd T leaves the last pair with one block
-  const int q0 = (2 * pair + (own ? b : 0)) * 32;
-
-  char* kimg = smem;                                               // [n][32] bf16
-  char* vimg = smem + (size_t)a.n * 64;                            // [n][32] bf16
-  char* qd = smem + (size_t)a.n * 128;                             // 2 blocks x {Q [32][32], dO [32][32]} bf16
-
-  half4_t* bias_l = (half4_t*)(smem + (size_t)a.n * 128 + 8192);   // [2][T][4][64] half4, accumulator layout as the forward
-  if (HAS_BIAS)
-    for (int id = tid; id < 2 * T * 256; id += NT) {
-      const int l = id & 63, j = (id >> 6) & 3, bt = id >> 8, t = bt % T, bb = bt / T;
-      half4_t hv = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-      if (2 * pair + bb < T) {
-        const float4 v = *(const float4*)(a.bias + ((long)head * a.n + (2 * pair + bb) * 32 + (l & 31)) * a.n + 32 * t + 8 * j + 4 * (l >> 5));
-        hv[0] = (_Float16)(v.x * p.inv_scale); hv[1] = (_Float16)(v.y * p.inv_scale);
-        hv[2] = (_Float16)(v.z * p.inv_scale); hv[3] = (_Float16)(v.w * p.inv_scale);
-      }
-      bias_l[id] = hv;
-    }
-  f32x16 dbacc[TPW];
-#pragma unroll
-  for (int j = 0; j < TPW; ++j) zero_acc(dbacc[j]);
-
-  // staging: thread `tid` moves 16-byte pieces tid + 512 i of K and of V (piece = row * 4 + chunk) and one piece of Q / dO
-  const int npk = a.n * 4;
-  const int qd_blk = tid >> 8, qd_which = (tid >> 7) & 1, qd_row = (tid & 127) >> 2, qd_c = tid & 3;
-  const int qd_q = (2 * pair + (2 * pair + qd_blk < T ? qd_blk : 0)) * 32 + qd_row;
-  const uint32_t qd_src = qd_which ? (uint32_t)(qd_q * a.lddo + head * 32 + qd_c * 8) : (uint32_t)(qd_q * a.ldq + head * 32 + qd_c * 8);
-  const uint32_t qd_dst = (uint32_t)(qd_blk * 4096 + qd_which * 2048) + img_off<32>(qd_row, qd_c);
-  const long kseq = (long)a.n * a.ldk, vseq = (long)a.n * a.ldv, qseq = (long)a.n * a.ldq, doseq = (long)a.n * a.lddo;
-  const long stat0 = (long)head * a.n + q0 + r, statseq = (long)a.heads * a.n;
-
-  u32x4 kst[NPK], vst[NPK], qdst = {0u, 0u, 0u, 0u};
-  float nlse2 = 0.f, delta = 0.f, nlse2_n = 0.f, delta_n = 0.f;
-  auto ld_staged = [&](long seq) {
-    const bf16_t* kb = a.k + seq * kseq + head * 32;
-    const bf16_t* vb = a.v + seq * vseq + head * 32;
-#pragma unroll
-    for (int i = 0; i < NPK; ++i) {
-      const int id = tid + NT * i;
-      if (id < npk) {
-        kst[i] = *(const u32x4*)(kb + (uint32_t)((id >> 2) * a.ldk + (id & 3) * 8));
-        vst[i] = *(const u32x4*)(vb + (uint32_t)((id >> 2) * a.ldv + (id & 3) * 8));
-      }
-    }
-    if (NT == 512 || tid < 512) qdst = qd_which ? *(const u32x4*)(a.dO + seq * doseq + qd_src) : *(const u32x4*)(a.q + seq * qseq + qd_src);
-    nlse2_n = -a.lse[seq * statseq + stat0] * kLog2e;
-    delta_n = a.delta[seq * statseq + stat0];
-  };
-  auto st_staged = [&]() {
-#pragma unroll
-    for (int i = 0; i < NPK; ++i) {
-      const int id = tid + NT * i;
-      if (id < npk) {
-        *(u32x4*)(kimg + img_off<32>(id >> 2, id & 3)) = kst[i];
-        *(u32x4*)(vimg + img_off<32>(id >> 2, id & 3)) = vst[i];
-      }
-    }
-    if (NT == 512 || tid < 512) *(u32x4*)(qd + qd_dst) = qdst;
-    nlse2 = nlse2_n;
-    delta = delta_n;
-  };
-
-  ld_staged(seq0);
-  st_staged();
-  __syncthreads();
-  for (int seq = seq0; seq < seq1; ++seq) {
-    const bf16x8 qf0 = row_frag<32>(qd + b * 4096, 0, 0, lane), qf1 = row_frag<32>(qd + b * 4096, 0, 1, lane);
-    const bf16x8 df0 = row_frag<32>(qd + b * 4096 + 2048, 0, 0, lane), df1 = row_frag<32>(qd + b * 4096 + 2048, 0, 1, lane);
-    ld_staged(seq + 1 < seq1 ? seq + 1 : seq);                     // consumed after this sequence's tiles
-    if (own) {
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const int t = g + G * j;
-        if (t < T) {
-          f32x16 S, dP;
-          if (HAS_BIAS) {
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const half4_t hb = bias_l[((b * T + t) * 4 + jj) * 64 + lane];
-              S[4 * jj] = (float)hb[0]; S[4 * jj + 1] = (float)hb[1]; S[4 * jj + 2] = (float)hb[2]; S[4 * jj + 3] = (float)hb[3];
-            }
-          } else {
-            zero_acc(S);
-          }
-          zero_acc(dP);
-          S = mfma32(row_frag<32>(kimg, 32 * t, 0, lane), qf0, S);
-          S = mfma32(row_frag<32>(kimg, 32 * t, 1, lane), qf1, S);
-          dP = mfma32(row_frag<32>(vimg, 32 * t, 0, lane), df0, dP);
-          dP = mfma32(row_frag<32>(vimg, 32 * t, 1, lane), df1, dP);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const float pr = exp2_fast(fmaf(S[i], p.c1, nlse2));
-            dbacc[j][i] = fmaf(pr, dP[i] - delta, dbacc[j][i]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    __syncthreads();                                               // every wave is done with the images
-    st_staged();
-    __syncthreads();
-  }
-
-  // flush: dense rows, or the relative-position table through an LDS copy of it (the images are idle now)
-  const int q = q0 + r;
-  if (a.dbias_dense) {
-    if (own)
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const int t = g + G * j;
-        if (t < T)
-#pragma unroll
-          for (int i = 0; i < 16; ++i)
-            atomicAdd(a.dbias_dense + ((long)head * a.n + q) * a.n + 32 * t + acc_row(i, half), dbacc[j][i]);
-      }
-  } else {
-    float* table = (float*)smem;
-    for (int i = tid; i < a.table_size; i += NT) table[i] = 0.f;
-    __syncthreads();
-    if (own) {
-      const int yq = a.grid_w > 0 ? q / a.grid_w : 0, xq = a.grid_w > 0 ? q % a.grid_w : 0;
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const int t = g + G * j;
-        if (t < T)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = 32 * t + acc_row(i, half);
-            int ti;
-            if (a.grid_w > 0) {
-              const int yk = key / a.grid_w, xk = key % a.grid_w;
-              ti = (yq - yk + a.grid_h - 1) * (2 * a.grid_w - 1) + (xq - xk + a.grid_w - 1);
-            } else {
-              ti = a.relidx[(long)q * a.n + key];
-            }
-            atomicAdd(&table[ti], dbacc[j][i]);
-          }
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < a.table_size; i += NT) {
-      const float v = table[i];
-      if (v != 0.f) atomicAdd(a.dbias_table + (long)head * a.table_size + i, v);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // backward pass 2: dK, dV.  Workgroup = (head, group of KB 32-key blocks, chunk of sequences); a wave owns whole sequences.
 // Lane = key, accumulator rows = queries: P and dS come out as the B operands of dV^T += dO^T P and dK^T += Q^T dS.
 // ------------------------------------------------------------------------------------------------
@@ -820,56 +647,36 @@ int ws_launch(K kernel, const WsArgs& p, int nblocks, int nw, size_t lds, hipStr
 
 template <int NW, int QB, int KB, bool ROWLD>
 int ws_bwd_launch(const AttnArgs& a, hipStream_t st) {
-  int nb1 = 0, nb2 = 0, nb3 = 0;
+  int nb1 = 0, nb2 = 0, nbf = 0, nbf12 = 0;
   const WsArgs p1 = ws_plan(a, QB, NW, &nb1);
   const WsArgs p2 = ws_plan(a, KB, NW, &nb2);
-  WsArgs p3 = ws_plan(a, 2, 1, &nb3);                              // d(bias): every wave walks the whole chunk
+  const WsArgs pf = ws_plan(a, 1, NW, &nbf), pf12 = ws_plan(a, 1, 12, &nbf12);
   const bool table = a.dbias_table != nullptr, dense = a.dbias_dense != nullptr;
   const bool hb = a.bias != nullptr, db = table || dense;
-  const size_t lds1 = (size_t)(hb ? QB * p1.T : 0) * 2048 + (size_t)NW * (ROWLD ? 8192 : 4096);
+  constexpr size_t IMG = ROWLD ? 4096 : 2048;                      // K (+ V) image bytes per wave and buffer
+  const size_t lds1 = (size_t)(hb ? QB * p1.T : 0) * 2048 + (size_t)NW * 2 * IMG;
   const size_t lds2 = (size_t)(hb ? KB * p2.T : 0) * 2048 + (size_t)NW * (4096 + (size_t)a.n * 8);
-  const size_t lds3 = (size_t)a.n * 128 + 8192 + (size_t)(hb ? 2 * p3.T : 0) * 2048;
-  if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return -1;
-  if (db) {
-    if (p3.T > 20 || lds3 > 160 * 1024) return -1;                 // 5 tiles and 5 staged pieces per wave at most
-    if (table && (size_t)a.table_size * 4 > (size_t)a.n * 128) return -1;
-    if (table && a.grid_w <= 0 && !a.relidx) return -1;
-  }
-  // d(bias) inside the dQ pass (one query block per workgroup, tiles under LDS locks) when it fits; else its own pass
-  int nbf = 0;
-  const WsArgs pf = ws_plan(a, 1, NW, &nbf);
-  const size_t ldsf = (size_t)(hb ? pf.T : 0) * 2048 + (size_t)pf.T * 4096 + 128 + (size_t)NW * (ROWLD ? 4096 : 2048);
-  const bool fused = db && ldsf <= 160 * 1024 && (!table || (size_t)a.table_size * 4 <= (size_t)NW * 2048) &&
-                     !CTCLIP_KNOB("CTCLIP_ATTN_WS_DBIAS_PASS");
+  // with a bias gradient: one query block per workgroup, its d(bias) tiles in LDS, as many waves as still have room
+  const size_t ldsf = (size_t)(hb ? pf.T : 0) * 2048 + (size_t)pf.T * 4096 + 128 + (size_t)NW * IMG;
+  const size_t ldsf12 = ldsf + (size_t)(12 - NW) * IMG;
+  if (lds2 > 160 * 1024 || (db ? ldsf : lds1) > 160 * 1024) return -1;
+  if (table && ((size_t)a.table_size * 4 > (size_t)NW * IMG || (a.grid_w <= 0 && !a.relidx))) return -1;
   int e;
-  int nbf12 = 0;
-  const WsArgs pf12 = ws_plan(a, 1, 12, &nbf12);
-  const size_t ldsf12 = ldsf + (size_t)(12 - NW) * (ROWLD ? 4096 : 2048);
-  // 12 waves (the fused kernel needs 156 registers) when their K / V images still fit: 4846 vs 5210 us per backward call
-  const bool w12 = fused && ldsf12 <= 160 * 1024 && (!table || (size_t)a.table_size * 4 <= (size_t)12 * 2048) &&
-                   !CTCLIP_KNOB("CTCLIP_ATTN_WS_FUSED_W8");
-  if (w12) {
-    e = hb ? ws_launch(ws_bwd_dq_kernel<true, 1, 12, ROWLD, true>, pf12, nbf12, 12, ldsf12, st)
-           : ws_launch(ws_bwd_dq_kernel<false, 1, 12, ROWLD, true>, pf12, nbf12, 12, ldsf12, st);
-  } else if (fused) {
-    e = hb ? ws_launch(ws_bwd_dq_kernel<true, 1, NW, ROWLD, true>, pf, nbf, NW, ldsf, st)
-           : ws_launch(ws_bwd_dq_kernel<false, 1, NW, ROWLD, true>, pf, nbf, NW, ldsf, st);
+  if (db) {
+    // 12 waves (the kernel needs 156 registers): 4846 vs 5210 us per backward call at 1536 x 8 x 576 x 32
+    const bool w12 = ldsf12 <= 160 * 1024 && !CTCLIP_KNOB("CTCLIP_ATTN_WS_FUSED_W8");
+    if (w12) {
+      e = hb ? ws_launch(ws_bwd_dq_kernel<true, 1, 12, ROWLD, true>, pf12, nbf12, 12, ldsf12, st)
+             : ws_launch(ws_bwd_dq_kernel<false, 1, 12, ROWLD, true>, pf12, nbf12, 12, ldsf12, st);
+    } else {
+      e = hb ? ws_launch(ws_bwd_dq_kernel<true, 1, NW, ROWLD, true>, pf, nbf, NW, ldsf, st)
+             : ws_launch(ws_bwd_dq_kernel<false, 1, NW, ROWLD, true>, pf, nbf, NW, ldsf, st);
+    }
   } else {
     e = hb ? ws_launch(ws_bwd_dq_kernel<true, QB, NW, ROWLD, false>, p1, nb1, NW, lds1, st)
            : ws_launch(ws_bwd_dq_kernel<false, QB, NW, ROWLD, false>, p1, nb1, NW, lds1, st);
   }
   if (e) return e;
-  if (db && !fused) {
-    // 12 waves (three per SIMD, three key tiles each) up to 18 tiles; 8 waves with five tiles each beyond
-    if (p3.T <= 18) {
-      e = hb ? ws_launch(ws_bwd_dbias_kernel<true, 3, 3, 12>, p3, nb3, 12, lds3, st)
-             : ws_launch(ws_bwd_dbias_kernel<false, 3, 3, 12>, p3, nb3, 12, lds3, st);
-    } else {
-      e = hb ? ws_launch(ws_bwd_dbias_kernel<true, 5, 5, 8>, p3, nb3, 8, lds3, st)
-             : ws_launch(ws_bwd_dbias_kernel<false, 5, 5, 8>, p3, nb3, 8, lds3, st);
-    }
-    if (e) return e;
-  }
   return hb ? ws_launch(ws_bwd_dkv_kernel<true, KB, NW>, p2, nb2, NW, lds2, st)
             : ws_launch(ws_bwd_dkv_kernel<false, KB, NW>, p2, nb2, NW, lds2, st);
 }

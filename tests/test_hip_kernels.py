@@ -423,7 +423,8 @@ def attn_ref(q, k, v, bias, mask, scale):
     (7, 320, 3, 32, True, False),      # sequence-persistent kernels, 10 tiles over 8 waves (2 + 1 per wave)
     (5, 256, 2, 32, False, False),     # sequence-persistent kernels without a bias
     (4, 160, 2, 32, True, False),      # 5 tiles: the last query-block / key-block pair of a workgroup is half empty
-    (2, 640, 1, 32, True, False),      # 20 tiles: wave-per-sequence forward, backward falls back to the sequence-persistent kernels
+    (2, 640, 1, 32, True, False),      # 20 tiles: the fused dQ + d(bias) pass only has room for 8 waves here
+    (2, 704, 1, 32, True, False),      # 22 tiles: forward by the wave-per-sequence kernel, backward by the per-sequence kernels (LDS)
     (5, 24, 3, 32, False, True),       # one-wave fused backward: masked keys, 15 (sequence, head) items over 8-wave groups
     (3, 32, 2, 32, True, False),       # one-wave fused backward at its largest row count, bias as an input only
 ])
