@@ -409,7 +409,7 @@ def main():
                 d["ms"] += ms; d["flops"] += w.get("flops", 0.0); d["bytes"] += w["bytes"]; d["launches"] += 1
         pmc_names = {"patch_embed_fwd": ("patch_ln_fwd_fast",), "patch_embed_bwd": ("patch_ln_bwd_fast",),
                      "spatial_attention_fwd": ("ws_fwd_kernel",), "vq_search": ("vq_topk3_kernel",),
-                     "spatial_attention_bwd": ("ws_bwd_dq_kernel", "ws_bwd_dbias_kernel", "ws_bwd_dkv_kernel")}
+                     "spatial_attention_bwd": ("ws_bwd_dq_kernel", "ws_bwd_dkv_kernel")}
         for tag, d in tags.items():
             if d["ms"] <= 0:
                 continue
