@@ -501,6 +501,39 @@ def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask, monkeypatch):
         check("attn dbias 2-D grid table", dt2, ref2, 3e-2)
 
 
+# ---------------------------------------------------------------------------------------------- dropout (text encoder)
+def test_dropout_kernels_share_one_counter_based_stream(hip):
+    """ctclip_dropout_keep / _add / _bwd evaluate the same keep(seed, offset + i): forward, backward and the materialised
+    flags agree element for element, different offsets and seeds give different flags, the keep rate is 1 - p."""
+    n, p, seed, off = 1 << 20, 0.1, 987654321, 7 << 40
+    keep = torch.empty(n, dtype=torch.uint8, device=DEV)
+    hip.dropout_keep(keep, n, p, seed, off)
+    rate = float(keep.float().mean())
+    assert abs(rate - (1 - p)) < 5 * math.sqrt(p * (1 - p) / n), rate
+    x, br, g = rnd(n, seed=70), rnd(n, seed=71), rnd(n, seed=72)
+    out = torch.empty_like(x)
+    hip.dropout_add(x, br, out, n, p, seed, off)
+    assert torch.allclose(out, x + keep.float() * (br * (1.0 / (1.0 - p))), rtol=1e-6, atol=1e-6)
+    assert torch.equal(out[keep == 0], x[keep == 0])
+    d32 = torch.empty_like(g)
+    d16 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    hip.dropout_bwd(g, d32, d16, n, p, seed, off)
+    assert torch.allclose(d32, keep.float() * (g * (1.0 / (1.0 - p))), rtol=1e-6, atol=0) and bool((d32[keep == 0] == 0).all())
+    assert torch.equal(d16, d32.to(torch.bfloat16))
+    for s2, o2 in ((seed + 1, off), (seed, off + n)):
+        other = torch.empty_like(keep)
+        hip.dropout_keep(other, n, p, s2, o2)
+        agree = float((other == keep).float().mean())
+        assert abs(agree - (p * p + (1 - p) * (1 - p))) < 0.01, agree     # independent streams agree by chance only
+    # a sub-range of the counter space is the same stream: chunked evaluation is consistent
+    part = torch.empty(1000, dtype=torch.uint8, device=DEV)
+    hip.dropout_keep(part, 1000, p, seed, off + 12345)
+    assert torch.equal(part, keep[12345:13345])
+    zero = torch.empty(4096, dtype=torch.uint8, device=DEV)
+    hip.dropout_keep(zero, 4096, 0.0, seed, off)
+    assert bool(zero.all())
+
+
 # ---------------------------------------------------------------------------------------------- volume ingest
 @pytest.mark.parametrize("H,W,D,xy,z,target,i16", [
     (40, 36, 22, 0.9, 2.4, (48, 40, 30), False),     # up-sampling in every axis; crop in H/W, pad in D
