@@ -219,11 +219,13 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < PL_P; ++i) acc[a][i] = zero;
 
-  f32x4 nx[PL_P];
-  auto load_plane = [&](int t) {
+  // two planes in flight per thread (the next one and the one after): with one, 37 KiB of loads per CU are outstanding at
+  // a time and the sweep waits on HBM latency
+  f32x4 nx[PL_P], nx2[PL_P];
+  auto load_plane = [&](int t, f32x4 (&dst)[PL_P]) {
     const long row = ((b * g.T + t) * g.H + h_) * g.W;
 #pragma unroll
-    for (int i = 0; i < PL_P; ++i) nx[i] = (active && w0 + i < g.W) ? xv[(row + w0 + i) * g.d4 + c] : zero;
+    for (int i = 0; i < PL_P; ++i) dst[i] = (active && w0 + i < g.W) ? xv[(row + w0 + i) * g.d4 + c] : zero;
   };
   auto stage_plane = [&](int buf) {
     if (!active) return;
@@ -249,13 +251,14 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
     }
   };
 
-  load_plane(0);
+  load_plane(0, nx);
   __syncthreads();                                           // zero fill + weights visible
   stage_plane(0);
+  if (g.T > 1) load_plane(1, nx);
   __syncthreads();
   for (int tp = 0; tp < g.T; ++tp) {
     const int buf = tp & 1;
-    if (tp + 1 < g.T) load_plane(tp + 1);                    // in flight while this plane is consumed
+    if (tp + 2 < g.T) load_plane(tp + 2, nx2);               // in flight while this plane and the next are consumed
     const f32x4* pb = plane + buf * plane_f4;
     int wofs = 0;
     asm volatile("" : "+s"(wofs));                           // opaque zero: keeps the 27 weight reads inside the loop
@@ -295,6 +298,8 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < PL_P; ++i) { acc[0][i] = acc[1][i]; acc[1][i] = acc[2][i]; acc[2][i] = zero; }
     if (tp + 1 < g.T) stage_plane(buf ^ 1);
+#pragma unroll
+    for (int i = 0; i < PL_P; ++i) nx[i] = nx2[i];
     lds_only_barrier();
   }
   if (!FWD) {
