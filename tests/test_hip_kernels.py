@@ -501,6 +501,41 @@ def test_attention_fwd_bwd(hip, nseq, n, H, D, use_bias, use_mask, monkeypatch):
         check("attn dbias 2-D grid table", dt2, ref2, 3e-2)
 
 
+def test_spatial_attention_bias_gradient_under_lds_locks_is_reproducible(hip):
+    """The CT-ViT spatial shape with enough sequences that every wave of the fused dQ + d(bias) pass competes for the
+    per-tile LDS locks many times: repeated runs agree to f32 summation order, the relative-position table equals the
+    dense gradient scattered by index, dQ is bit-identical run to run."""
+    nseq, n, H, D, gh, gw = 192, 576, 8, 32, 24, 24
+    ld = H * D
+    unit = lambda t: torch.nn.functional.normalize(t.reshape(nseq * n, H, D), dim=-1).reshape(nseq * n, ld)
+    q, k = bf(unit(rnd(nseq * n, ld, seed=80)) * 8.0), bf(unit(rnd(nseq * n, ld, seed=81)))
+    v, do = bf(rnd(nseq * n, ld, seed=82)), bf(rnd(nseq * n, ld, seed=83))
+    bias = rnd(H, n, n, seed=84)
+    o = torch.empty_like(q)
+    lse = torch.empty(nseq, H, n, device=DEV)
+    hip.attn_fwd(q, k, v, o, lse, bias, None, nseq, n, H, D, ld, ld, ld, ld, 1.0)
+    dq, dk, dv = (torch.empty_like(q) for _ in range(3))
+    delta = torch.empty_like(lse)
+    R = (2 * gh - 1) * (2 * gw - 1)
+    runs = []
+    for _ in range(4):
+        dt = torch.zeros(H, R, device=DEV)
+        hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, None, None, None, dt, R, gh, gw, nseq, n, H, D,
+                     ld, ld, ld, ld, ld, ld, ld, ld, 1.0)
+        torch.cuda.synchronize()
+        runs.append((dt, dq.clone()))
+    for dt, dq_i in runs[1:]:
+        assert float((dt - runs[0][0]).abs().max() / runs[0][0].abs().max()) < 1e-5
+        assert torch.equal(dq_i, runs[0][1])
+    dense = torch.zeros(H, n, n, device=DEV)
+    hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, None, dense, None, None, 0, 0, 0, nseq, n, H, D,
+                 ld, ld, ld, ld, ld, ld, ld, ld, 1.0)
+    ii = torch.arange(n, device=DEV)
+    rel = (ii[:, None] // gw - ii[None] // gw + gh - 1) * (2 * gw - 1) + (ii[:, None] % gw - ii[None] % gw + gw - 1)
+    ref = torch.zeros(H, R, device=DEV).index_add_(1, rel.reshape(-1), dense.reshape(H, -1))
+    check("table vs scattered dense d(bias)", runs[0][0], ref, 1e-5)
+
+
 # ---------------------------------------------------------------------------------------------- dropout (text encoder)
 def test_dropout_kernels_share_one_counter_based_stream(hip):
     """ctclip_dropout_keep / _add / _bwd evaluate the same keep(seed, offset + i): forward, backward and the materialised
