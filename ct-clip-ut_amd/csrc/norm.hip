@@ -113,8 +113,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     const long yrow = swapped_row(row, swap_a, swap_c);           // dy lives in the forward's OUTPUT order
     const float4* dr = (const float4*)((const float*)dy_any + yrow * dim);
     const bf16_t* dr16 = (const bf16_t*)dy_any + yrow * dim;
-    float4 xh[LN_NV], gg[LN_NV];
+    float4 xh[LN_NV], gg[LN_NV], rres[LN_NV];
     float s1 = 0.f, s2 = 0.f;
+    // the residual-path terms are requested with the row itself, not after the two reductions: one memory round trip per
+    // row instead of two
+#pragma unroll
+    for (int i = 0; i < LN_NV; ++i) {
+      const int c = lane + i * 64;
+      rres[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < nv) {
+        if (dres) rres[i] = ((const float4*)(dres + (long)row * dim))[c];
+        if (DY16 && dres2) {
+          const float4 r2 = ld_bf16x4(dres2 + (long)row * dim + 4 * c);
+          rres[i].x += r2.x; rres[i].y += r2.y; rres[i].z += r2.z; rres[i].w += r2.w;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < LN_NV; ++i) {
       const int c = lane + i * 64;
@@ -138,14 +152,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
         o.y = rs * (gg[i].y - m1 - xh[i].y * m2);
         o.z = rs * (gg[i].z - m1 - xh[i].z * m2);
         o.w = rs * (gg[i].w - m1 - xh[i].w * m2);
-        if (dres) {
-          const float4 r = ((const float4*)(dres + (long)row * dim))[c];
-          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
-        if (DY16 && dres2) {
-          const float4 r = ld_bf16x4(dres2 + (long)row * dim + 4 * c);
-          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-        }
+        o.x += rres[i].x; o.y += rres[i].y; o.z += rres[i].z; o.w += rres[i].w;
         if (dx) ((float4*)(dx + (long)row * dim))[c] = o;
         if (dx16) {
           uint2 p;
