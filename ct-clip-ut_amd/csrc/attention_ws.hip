@@ -217,20 +217,37 @@ WsArgs ws_plan(const AttnArgs& a, int qb, int nw, int* nblocks) {
   p.T = a.n / 32;
   p.c1 = a.scale * kLog2e;
   p.inv_scale = 1.0f / a.scale;
-  // one workgroup per CU is resident (bias tiles + V images in LDS): ~8 rounds of workgroups, every wave of a workgroup
-  // with the same number of sequences
+  // One workgroup per CU is resident (bias tiles + images in LDS) and every workgroup pays a fixed price (bias fill, d(bias)
+  // flush), so: few rounds of workgroups, and the FULL-size chunks fill a whole number of rounds -- what is left over makes
+  // one short chunk whose workgroups finish early instead of a full-size tail.  Measured at 1536 sequences (forward /
+  // backward with the table, us): 8.4 even rounds 1770 / 4813; 216 sequences per workgroup (7 full chunks = 1.97 rounds of
+  // the 72 forward roles, 3.94 of the 144 dQ roles, + 24 left) 1697 / 4600; 192 (exactly 8 full chunks, 2.25 rounds) 1960 / 5328.
   const long roles = (long)((p.T + qb - 1) / qb) * a.heads;
-  long nchunks = (8L * cu_count_ws() + roles - 1) / roles;
-  if (nchunks < 1) nchunks = 1;
-  long chunk = (a.nseq + nchunks - 1) / nchunks;
-  chunk = (chunk + nw - 1) / nw * nw;
+  const long cus = cu_count_ws();
+  long nfull = 0;
+  double best = 0.0;
+  for (long r = 1; r <= 8; ++r) {
+    const long nf = r * cus / roles;                               // full-size chunks that fit r rounds
+    if (nf < 1) continue;
+    const double fill = (double)(roles * nf) / (double)(r * cus);
+    if (fill > best + 0.02) { best = fill; nfull = nf; }           // the fewest rounds among (nearly) equally tight fits
+  }
+  long chunk = nfull > 0 ? a.nseq / nfull : a.nseq;
+  chunk = chunk / nw * nw;                                         // every wave of a workgroup the same number of sequences
+  if (chunk < nw) {                                                // few sequences: as many chunks as fill ~8 rounds
+    long nchunks = (8 * cus + roles - 1) / roles;
+    if (nchunks < 1) nchunks = 1;
+    chunk = (a.nseq + nchunks - 1) / nchunks;
+    chunk = (chunk + nw - 1) / nw * nw;
+  }
   if (const char* e = getenv("CTCLIP_ATTN_SP_CHUNK")) {            // test hook (include/ctclip_hip.h): ragged chunks
     const int forced = atoi(e);
     if (forced > 0) chunk = forced;
   }
   if (chunk > a.nseq) chunk = a.nseq;
+  if (chunk < 1) chunk = 1;
   p.chunk = (int)chunk;
-  nchunks = (a.nseq + chunk - 1) / chunk;
+  const long nchunks = (a.nseq + chunk - 1) / chunk;
   p.nchunks = (int)nchunks;
   *nblocks = (int)(roles * nchunks);
   return p;
