@@ -226,13 +226,20 @@ def _c(t):
 
 
 def grad_slot(p, note=True):
-    """-> (buffer, direct).  Every gradient kernel ACCUMULATES (f32 atomics), so when the parameter already owns a
-    contiguous f32 .grad (the flat arena of ctclip_hip.optim.HipAdam pre-binds one) the kernels add straight into
-    it and the Function returns None for that input: no zero-fill, no extra `grad += new` pass per tensor."""
+    """-> (buffer, direct).  Every gradient kernel ACCUMULATES, so when the parameter already owns a contiguous f32 .grad
+    (the flat arena of ctclip_hip.optim.HipAdam pre-binds one) the kernels add straight into it and the Function returns
+    None for that input: no zero-fill, no extra `grad += new` pass per tensor.
+
+    A parameter whose optimiser averages gradients across ranks carries its listener (`_ctclip_sync`, a GradSync): it is told
+    BEFORE the slot is handed out (a second backward in one step must not write into a slice RCCL is still reducing) and,
+    with `note`, again once the running backward has issued all of its kernels (announce_grads)."""
     g = p.grad
     if g is not None and g.dtype == F32 and g.is_contiguous() and g.shape == p.shape and g.device == p.device:
-        if note and grad_ready_hook is not None:
-            _issued.append(p)
+        sync = getattr(p, "_ctclip_sync", None)
+        if sync is not None:
+            sync.before_write(p)
+            if note:
+                _issued.append(p)
         return g, True
     return torch.zeros(p.shape, dtype=F32, device=p.device), False
 
@@ -241,12 +248,12 @@ def _ret(buf, direct):
     return None if direct else buf
 
 
-# Optional callback(param) fired by a backward as soon as a parameter's gradient has been fully ISSUED into its arena slot.
-# GradSync installs it to start that bucket's RCCL all-reduce early (overlap with the rest of backward).  Parameters whose
-# gradient autograd delivers (a Function that returns it) are reported by a post-accumulate hook instead; the ones below
-# accumulate in place and return None, so the Function itself has to say when it is done: grad_slot() notes the parameter,
+# Gradient-ready reports.  GradSync (optim.py) tags every parameter of ITS optimiser with `_ctclip_sync = self` -- a
+# per-optimiser registration, so several trainers can live in one process -- to start that parameter's bucket all-reduce as
+# soon as its gradient has been fully ISSUED into the arena (overlap with the rest of backward).  Parameters whose gradient
+# autograd delivers (a Function that returns it) are reported by a post-accumulate hook instead; the Functions below
+# accumulate in place and return None, so they have to say themselves when they are done: grad_slot() notes the parameter,
 # announce_grads() at the end of the backward reports every noted one.
-grad_ready_hook = None
 _issued = []
 
 
@@ -254,10 +261,10 @@ def announce_grads():
     if _issued:
         ps = list(_issued)
         _issued.clear()
-        hook = grad_ready_hook
-        if hook is not None:
-            for p in ps:
-                hook(p)
+        for p in ps:
+            sync = getattr(p, "_ctclip_sync", None)
+            if sync is not None:
+                sync.param_ready(p)
 
 
 def announces(backward):
@@ -272,8 +279,9 @@ def announces(backward):
 
 
 def _grad_ready(p, direct):
-    if direct and grad_ready_hook is not None:
-        grad_ready_hook(p)
+    sync = getattr(p, "_ctclip_sync", None)
+    if direct and sync is not None:
+        sync.param_ready(p)
 
 
 def _tag16(t32, t16):
@@ -376,8 +384,7 @@ class PegFn(Function):
         gw, dw_direct = grad_slot(p_w, note=False)
         gb, db_direct = grad_slot(p_b, note=False)
         if dw_direct and db_direct:
-            if grad_ready_hook is not None:
-                _issued.extend((p_w, p_b))
+            _issued.extend(q for q in (p_w, p_b) if getattr(q, "_ctclip_sync", None) is not None)
             # HBM-bound and off the critical path: on the side stream it shares the chip with the matrix-bound GEMMs of the
             # layer whose backward comes next; the tap-major result is folded into the [d,1,3,3,3] gradient there too
             def peg_wgrad():
@@ -535,7 +542,7 @@ class FeedForwardFn(Function):
         M = x2.shape[0]
         I, Ip = sh["inner"], sh["inner_p"]
         n2, _, mean, rstd = layernorm(x2, ln_w.detach(), ln_b.detach(), 1e-5)
-        h = torch.empty(M, 2 * Ip, dtype=BF16, device=x.device)    # [val 64 | gate 64 | ...] blocks, kept for the backward
+        h = torch.empty(M, 2 * Ip, dtype=BF16, device=x.device)    # [val 32 | gate 32 | ...] blocks (GEGLU_BLOCK), kept for the backward
         g = torch.empty(M, Ip, dtype=BF16, device=x.device)
         hip.gemm_bf16_geglu(n2, sh["w1"], h, g, M, Ip, dim, n2.stride(0), sh["w1"].stride(0), 2 * Ip, Ip)
         y = gemm(g, sh["w2"], M, dim, Ip, out_dtype=F32, resid=x2 if residual else None)
@@ -800,6 +807,8 @@ class VisualLatentFn(Function):
         w = ctx.w
         if w.grad is not None and w.grad.is_contiguous() and w.grad.dtype == F32:
             # accumulate the (dim_latent x dim_image) weight gradient straight into the arena-backed .grad
+            if getattr(w, "_ctclip_sync", None) is not None:
+                w._ctclip_sync.before_write(w)
             gemm(dyb, a16, L, Fdim, B, a_kmajor=False, b_kmajor=False, out=w.grad, accumulate=True)
             dw = None
             _grad_ready(w, True)            # 53 % of all gradient bytes, ready at the very start of backward

@@ -42,6 +42,14 @@ class HipAdam(torch.optim.Optimizer):
                  amsgrad=False, maximize=False, **torch_adam_flags):
         if amsgrad or maximize:
             raise NotImplementedError("amsgrad / maximize are not implemented by the fused HIP step")
+        # torch.optim.Adam's implementation switches: `fused` / `foreach` choose between equivalent implementations (this one
+        # is always fused); the two that change semantics cannot be honoured, and anything else is a typo
+        unknown = set(torch_adam_flags) - {"fused", "foreach", "capturable", "differentiable"}
+        if unknown:
+            raise TypeError(f"HipAdam got unexpected keyword arguments {sorted(unknown)}")
+        for k in ("capturable", "differentiable"):
+            if torch_adam_flags.get(k):
+                raise NotImplementedError(f"{k}=True is not supported by the fused HIP step")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **_TORCH_ADAM_KEYS,
                         decoupled_weight_decay=bool(decoupled))
         super().__init__(params, defaults)
@@ -50,6 +58,7 @@ class HipAdam(torch.optim.Optimizer):
         self._arenas = []       # per group: dict(p=, g=, m=, v=, params=[...], offs=[...]) or None
         self._gnorm_sq = None
         self.last_grad_norm_sq = None
+        self._grad_listeners = []   # GradSync objects averaging this optimiser's arenas (joined / re-armed by zero_grad)
 
     # -- arena construction (lazy: parameters may be moved to the GPU after the optimiser was created) ------
     def _build(self):
@@ -93,7 +102,12 @@ class HipAdam(torch.optim.Optimizer):
 
     def _bind_grads(self, adopt: bool):
         """Make every parameter's .grad the arena view again.  adopt: a gradient somebody assigned as a new tensor
-        (`p.grad = t`, the torch.optim contract) is copied into its slot first; a grad of None counts as zero."""
+        (`p.grad = t`, the torch.optim contract) is copied into its slot first; a grad of None counts as zero.
+
+        Difference from torch.optim.Adam, by design of the flat arena: a parameter that HAS a slot is stepped every step with
+        the one global step count -- a zero gradient still decays its moments (and applies weight decay) -- where torch
+        skips a parameter whose grad is None and keeps a per-parameter step.  Parameters that never receive a gradient on
+        this path are the ones tagged mark_unused(): they have no slot, no state and are never touched, like torch's."""
         for a in self._arenas:
             if a is None:
                 continue
@@ -113,6 +127,8 @@ class HipAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False):
         if not self._built:
             self._build()
+        for sync in self._grad_listeners:
+            sync.reset()
         for a in self._arenas:
             if a is not None:
                 a["g"].zero_()
@@ -236,14 +252,21 @@ class GradSync:
     ("buckets") of the flat gradient arenas.  Replaces DistributedDataParallel's per-bucket copies (reference
     CTClipTrainer.py:62-69,109-115; fired from :196).
 
-    Overlap with backward: every parameter reports once per step when its gradient has been ISSUED into the arena --
-    through `ops.grad_ready_hook` from the Functions that accumulate in place, through a post-accumulate hook for
-    gradients autograd delivers.  A bucket whose parameters have all reported is all-reduced at once, so buckets leave in
-    reverse-autograd order while the rest of backward runs.  Gradient kernels run on two streams (weight gradients on
-    ops' side stream), so the collective is issued from the side stream after it has been made to wait for the main
-    stream: RCCL's stream then orders after everything issued on either.  Whatever has not reported when backward
-    returns is reduced by all_reduce_grads().  With 7 xGMI peers a few large collectives keep every link busy;
-    `bucket_mb` sizes them."""
+    Overlap with backward: every parameter of THIS optimiser is tagged with `_ctclip_sync = self` (a per-optimiser
+    registration: several trainers may live in one process) and reports when its gradient has been ISSUED into the arena
+    -- through ops.grad_slot()/announce_grads() from the Functions that accumulate in place, through a post-accumulate hook
+    for gradients autograd delivers.  A bucket whose parameters have all reported is all-reduced at once, so buckets leave
+    in reverse-autograd order while the rest of backward runs.  Whatever has not reported when backward returns is reduced
+    by all_reduce_grads().  With 7 xGMI peers a few large collectives keep every link busy; `bucket_mb` sizes them.
+
+    More than one backward per step (gradient accumulation, an attribution backward through the model, a step aborted
+    between backward and all_reduce_grads):
+      * `with sync.no_sync():` -- reports are ignored, nothing is launched: the micro-batches before the last one;
+      * a parameter that is about to be written again after its bucket has left (`before_write`, called by grad_slot() and a
+        tensor hook BEFORE the gradient kernels are issued) first makes the current stream wait for that collective and
+        re-arms the bucket: the slice then holds avg(g1), the new local gradient is added on top, and the second
+        all-reduce(avg) yields avg(g1) + avg(g2) -- no write into a slice RCCL is still reducing, no element reduced twice;
+      * HipAdam.zero_grad() joins whatever is still in flight and re-arms every bucket before it clears the arena."""
 
     def __init__(self, optimizer: HipAdam, bucket_mb: int = 64, group=None, overlap: bool = True):
         self.opt, self.group = optimizer, group
@@ -252,15 +275,25 @@ class GradSync:
         self._buckets = None        # list of dict(ai, start, stop, n, pending, handle)
         self._bucket_of = {}
         self._hooks = []
-        if overlap:
-            ops.grad_ready_hook = self.param_ready
+        self._tagged = []
+        self._defer = False
+        listeners = getattr(optimizer, "_grad_listeners", None)
+        if listeners is not None:
+            listeners.append(self)
 
     def close(self):
+        self.reset()
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        if ops.grad_ready_hook == self.param_ready:
-            ops.grad_ready_hook = None
+        for p in self._tagged:
+            if getattr(p, "_ctclip_sync", None) is self:
+                del p._ctclip_sync
+        self._tagged = []
+        self._buckets, self._bucket_of = None, {}
+        listeners = getattr(self.opt, "_grad_listeners", None)
+        if listeners is not None and self in listeners:
+            listeners.remove(self)
 
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
@@ -269,6 +302,20 @@ class GradSync:
         """Collectives run whenever a process group exists -- also at world size 1, where they are no-ops on the data but
         the RCCL path is the one exercised."""
         return dist.is_available() and dist.is_initialized()
+
+    def no_sync(self):
+        """Context manager for the micro-batches of a gradient-accumulation step that must not start collectives (DDP's
+        `no_sync`): gradients only accumulate locally; the backward of the last micro-batch, outside of it, reduces."""
+        sync = self
+
+        class _NoSync:
+            def __enter__(self_):
+                self_.was, sync._defer = sync._defer, True
+
+            def __exit__(self_, *exc):
+                sync._defer = self_.was
+                return False
+        return _NoSync()
 
     # -- plan ---------------------------------------------------------------------------------------------------
     def _plan(self):
@@ -299,17 +346,30 @@ class GradSync:
                 self._bucket_of[id(p)] = cur
                 if cur["stop"] - cur["start"] >= self.bucket_elems:
                     cur = None
-                if self.overlap and hasattr(p, "register_post_accumulate_grad_hook"):
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self.param_ready))
+                if self.overlap:
+                    p._ctclip_sync = self
+                    self._tagged.append(p)
+                    if hasattr(p, "register_post_accumulate_grad_hook"):
+                        # autograd-delivered gradients: told before the accumulation (tensor hook) and after it.  The
+                        # engine also runs these hooks with an undefined gradient for a parameter whose Function returned
+                        # None (the in-place accumulating ones): nothing is written then
+                        self._hooks.append(p.register_hook(
+                            lambda g, p=p: self.before_write(p) if g is not None else None))
+                        self._hooks.append(p.register_post_accumulate_grad_hook(self.param_ready))
         for b in self._buckets:
             b["pending"] = b["n"]
+
+    def prepare(self):
+        """Plan the buckets and tag the parameters now (otherwise done by the first report / all_reduce_grads)."""
+        if self._buckets is None and self.active():
+            self._plan()
 
     def _flat(self, b):
         arenas = getattr(self.opt, "_arenas", None)
         g = arenas[b["ai"]]["g"] if arenas is not None else self.opt.flat_grads()[b["ai"]]
         return g[b["start"]:b["stop"]]
 
-    # -- launch -------------------------------------------------------------------------------------------------
+    # -- launch / join -------------------------------------------------------------------------------------------
     def _launch(self, b):
         chunk = self._flat(b)
         if chunk.is_cuda and dist.get_backend(self.group) == "nccl":
@@ -325,9 +385,29 @@ class GradSync:
         else:                                                # gloo: no AVG
             b["handle"] = (dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk)
 
+    def _join(self, b):
+        """Wait for b's collective (the current stream then orders after RCCL's) and re-arm the bucket."""
+        h = b["handle"]
+        if h is not None:
+            if isinstance(h, tuple):
+                h[0].wait()
+                h[1].div_(self.world())
+            else:
+                h.wait()
+        b["handle"] = None
+        b["pending"] = b["n"]
+
+    def before_write(self, param):
+        """`param`'s arena slot is about to be written by gradient kernels that have NOT been issued yet."""
+        if self._buckets is None:
+            return
+        b = self._bucket_of.get(id(param))
+        if b is not None and b["handle"] is not None:
+            self._join(b)                                    # a second backward in this step: see the class docstring
+
     def param_ready(self, param):
-        """`param`'s gradient kernels have been issued (once per parameter per step)."""
-        if not self.active():
+        """`param`'s gradient kernels have been issued."""
+        if self._defer or not self.active():
             return
         if self._buckets is None:
             self._plan()
@@ -341,22 +421,21 @@ class GradSync:
     # kept for callers of the round-1 name
     early_reduce = param_ready
 
+    def reset(self):
+        """Join every collective still in flight and re-arm all buckets (HipAdam.zero_grad calls this before it clears the
+        arena: a step that was aborted after its backward must not leave a reduce running over memory being zeroed)."""
+        if self._buckets:
+            for b in self._buckets:
+                self._join(b)
+
     def all_reduce_grads(self):
         """Reduce what is left, wait for everything (the current stream then orders after RCCL's), reset for the next step."""
         if not self.active():
             return
         if self._buckets is None:
             self._plan()
-        w = self.world()
         for b in self._buckets:
             if b["handle"] is None:
                 self._launch(b)
         for b in self._buckets:
-            h = b["handle"]
-            if isinstance(h, tuple):
-                h[0].wait()
-                h[1].div_(w)
-            else:
-                h.wait()
-            b["handle"] = None
-            b["pending"] = b["n"]
+            self._join(b)

@@ -95,6 +95,7 @@ class CTClipTrainer(nn.Module):
                 mark_unused(p)
         self.optim = get_optimizer(self.model.parameters(), lr=lr, wd=wd)      # reference :107
         self.grad_sync = GradSync(self.optim)
+        self.grad_sync.prepare()               # with a process group: plan the buckets, tag this optimiser's parameters
         if self.accelerator.distributed:                                       # DDP broadcasts rank-0 weights at wrap time
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 dist.broadcast(t.data, src=0)

@@ -157,7 +157,7 @@ def _hook_driven_buckets(rank):
         torch.testing.assert_close(a["g"][o:o + pr.numel()].view(pr.shape), w / WORLD, rtol=1e-5, atol=1e-6)
     assert all(b["handle"] is None and b["pending"] == b["n"] for b in sync._buckets)   # armed for the next step
     sync.close()
-    assert ops.grad_ready_hook is None
+    assert all(not hasattr(pr, "_ctclip_sync") for pr in params) and not opt._grad_listeners
 
 
 def test_gradsync_buckets_leave_during_backward_and_average_once():
@@ -292,3 +292,170 @@ def _sharded_weak_scaling_units(rank):
 
 def test_bench_shards_units_and_takes_max_time():
     _run(_sharded_weak_scaling_units)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _two_backwards_per_step(rank):
+    """More than one backward between zero_grad() and step() (gradient accumulation, an attribution backward through the
+    model): a bucket that has already left is joined and re-armed BEFORE the second backward writes into its slice
+    (GradSync.before_write), so the final arena holds avg(g1 + g2) -- nothing is reduced twice, nothing is left local --
+    and `no_sync()` keeps the first micro-batch from starting collectives at all.  zero_grad() joins what an aborted step
+    left in flight."""
+    from ctclip_hip import ops
+    from ctclip_hip.optim import GradSync, HipAdam
+    torch.manual_seed(0)                                                       # same weights on both ranks
+    lin1, lin2 = torch.nn.Linear(6, 5), torch.nn.Linear(5, 64, bias=False)
+    direct = torch.nn.Parameter(torch.zeros(8))
+    params = [*lin1.parameters(), *lin2.parameters(), direct]
+    torch.manual_seed(20 + rank)                                               # different data per rank
+    xs = [torch.randn(3, 6), torch.randn(3, 6)]
+
+    class InPlace(torch.autograd.Function):                                    # stands in for a HIP backward
+        @staticmethod
+        def forward(ctx, x, p):
+            ctx.p = p
+            return x * 1.0
+
+        @staticmethod
+        @ops.announces
+        def backward(ctx, dy):
+            slot, is_direct = ops.grad_slot(ctx.p)
+            assert is_direct
+            slot += dy.sum() * torch.arange(8.0) * (rank + 1)
+            return dy, None
+
+    def loss_of(x):
+        return (InPlace.apply(lin2(torch.relu(lin1(x))), direct) ** 2).sum()
+
+    opt = HipAdam(params, lr=1e-3)
+    sync = GradSync(opt, bucket_mb=1)
+    sync.bucket_elems = 40
+    opt.zero_grad()
+    sync.prepare()
+    assert all(getattr(pr, "_ctclip_sync", None) is sync for pr in params)
+    a = opt._arenas[0]
+
+    def expected():                                                            # local sum of both micro-batches, then averaged
+        loc = torch.zeros_like(a["g"])
+        for x in xs:
+            for pr in params:
+                pr.grad = None
+            direct.grad = torch.zeros(8)                                       # the in-place Function needs a slot to add into
+            loss_of(x).backward()
+            for pr, o in zip(a["params"], a["offs"]):
+                if pr is direct:                                               # added in closed form below
+                    continue
+                loc[o:o + pr.numel()] += pr.grad.reshape(-1)
+        return loc
+
+    launched = []
+    real_launch = sync._launch
+    sync._launch = lambda b: (launched.append((b["start"], b["stop"])), real_launch(b))[1]
+
+    # (a) two plain backwards: buckets leave during the first, are joined + re-armed by the second, leave again
+    opt.zero_grad()
+    loss_of(xs[0]).backward()
+    n1 = len(launched)
+    assert n1 >= 1 and any(b["handle"] is not None for b in sync._buckets)
+    loss_of(xs[1]).backward()
+    assert len(launched) > n1                                                  # re-armed buckets were reduced again
+    sync.all_reduce_grads()
+    got_a = a["g"].clone()
+    assert all(b["handle"] is None and b["pending"] == b["n"] for b in sync._buckets)
+
+    # (b) the same step with no_sync() around the first micro-batch: every bucket leaves exactly once
+    opt.zero_grad()
+    launched.clear()
+    with sync.no_sync():
+        loss_of(xs[0]).backward()
+    assert not launched
+    loss_of(xs[1]).backward()
+    sync.all_reduce_grads()
+    assert len(launched) == len(sync._buckets)
+    got_b = a["g"].clone()
+
+    # (c) a step aborted after backward: zero_grad() joins the collectives in flight before it clears the arena
+    opt.zero_grad()
+    loss_of(xs[0]).backward()
+    assert any(b["handle"] is not None for b in sync._buckets)
+    opt.zero_grad()
+    assert all(b["handle"] is None and b["pending"] == b["n"] for b in sync._buckets)
+    assert float(a["g"].abs().max()) == 0.0
+
+    # expected: plain local sums (no hooks), one bare all-reduce
+    sync.close()
+    assert all(not hasattr(pr, "_ctclip_sync") for pr in params)
+    want = expected()
+    o_direct = next(o for pr, o in zip(a["params"], a["offs"]) if pr is direct)
+    with torch.no_grad():
+        for x in xs:
+            want[o_direct:o_direct + 8] += (2 * lin2(torch.relu(lin1(x)))).sum() * torch.arange(8.0) * (rank + 1)
+    dist.all_reduce(want)
+    want /= WORLD
+    torch.testing.assert_close(got_a, want, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got_b, want, rtol=1e-5, atol=1e-6)
+
+
+def test_gradsync_two_backwards_per_step_and_no_sync():
+    _run(_two_backwards_per_step)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _occlusion_window_sharding(rank):
+    """utils.visualizations.Visualizations._compute_occlusion (reference src/utils/visualizations.py:340-361,404-409): the
+    window list is cut into equal contiguous slices (windows beyond a multiple of the world size are DROPPED, as the
+    reference does), every rank scores its own slice, heat-map and count-map are summed onto rank 0 with one reduce each,
+    and only rank 0 returns a map.  The scorer is a linear stand-in (sim = <w, volume>), so the importance of a window is
+    known in closed form; the batched device-side accumulation and the collectives are the code under test."""
+    import numpy as np
+    import torch.nn.functional as F
+    from utils.visualizations import Visualizations
+
+    D, H, W = 8, 12, 12
+    gen = torch.Generator().manual_seed(3)
+    image = torch.randn(1, 1, D, H, W, generator=gen).clamp(-1, 1)
+    weight = torch.rand(D, H, W, generator=gen)                               # >= 0: occluding (-> -1) never raises the score
+    patch, stride = (4, 6, 6), (2, 3, 3)                                       # 3 x 3 x 3 = 27 windows: one is dropped at W = 2
+
+    class Scorer(torch.nn.Module):
+        gather_negatives = True
+
+        def encode_text(self, tokens):
+            return torch.zeros(1, 4)
+
+        def forward(self, text, vol, cls):
+            return ((vol[:, 0] * weight).sum(dim=(1, 2, 3)).reshape(-1, 1),)
+
+    class Acc:
+        is_main_process, process_index, num_processes, device = rank == 0, rank, WORLD, torch.device("cpu")
+
+    model = Scorer()
+    vis = Visualizations(model, Acc(), occlusion_batch=4)                      # 13 windows per rank: 3 full batches + 1
+    got = vis._compute_occlusion(image, {"input_ids": torch.zeros(1, 2, dtype=torch.long)}, None, patch, stride, 0.0)
+    assert model.gather_negatives is True                                      # restored
+    if rank != 0:
+        assert got is None
+        return
+    coords = [(d, h, w) for d in range(0, D - patch[0] + 1, stride[0]) for h in range(0, H - patch[1] + 1, stride[1])
+              for w in range(0, W - patch[2] + 1, stride[2])]
+    assert len(coords) == 27
+    kept = coords[:(len(coords) // WORLD) * WORLD]                             # reference :352-356
+    heat, count = torch.zeros(D, H, W), torch.zeros(D, H, W)
+    vol = image[0, 0]
+    for d, h, w in kept:
+        sl = (slice(d, d + patch[0]), slice(h, h + patch[1]), slice(w, w + patch[2]))
+        imp = float(((vol[sl] + 1) * weight[sl]).sum().clamp_min(0))          # original - occluded for the linear scorer
+        heat[sl] += imp
+        count[sl] += 1
+    count[count == 0] = 1
+    heat = heat / count
+    heat = (heat - heat.min()) / (heat.max() - heat.min() + 1e-8)
+    want = np.rot90(F.interpolate(heat[None, None], size=(D, H, W), mode="trilinear", align_corners=False)[0, 0].numpy(),
+                    k=-1, axes=(1, 2))
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-5
+    assert (count == 1).any() and float(count.max()) > 1                       # overlapping windows were exercised
+
+
+def test_occlusion_windows_are_sharded_and_reduced_to_rank_zero():
+    _run(_occlusion_window_sharding)

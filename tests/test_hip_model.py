@@ -52,6 +52,53 @@ def grad_parity(named, ref, rel_tol, label):
     assert glob_cos > 0.999 and glob_rel < rel_tol
 
 
+def same_trajectory(ref_state, got_state, codes_ref, codes_got, lr, steps, label):
+    """Two runs of the same training steps from the same state, executed by the same kernels: what may differ is the order of
+    the f32 atomic adds inside the order-dependent gradient sums (include/ctclip_hip.h names them).  Two mechanisms turn
+    that last-bit noise into visible differences, and both are bounded here instead of being ignored:
+      * Adam moves every element by ~lr * sign(g) in its first steps, so an element whose gradient IS rounding noise
+        (zero-initialised biases, BERT key biases the softmax is invariant to) may move the other way: allowed per element
+        is 2 lr per step, or 1e-3 of the tensor's peak if that is larger;
+      * the VQ nearest-code decision is an arg-max: weights that differ by ~lr can flip a genuine near-tie in a LATER step,
+        and a flipped token moves its two codebook rows by (1 - decay) of a unit vector.  The code decisions of both runs
+        are therefore compared first: if they are identical the codebook buffers must agree to 1e-4 of their peak; if a
+        near-tie flipped (at most 2 % of the decisions may), only the rows no flipped token touched are compared.
+    Returns the fraction of flipped decisions."""
+    flipped_codes = set()
+    n_dec = n_flip = 0
+    for a, b in zip(codes_ref, codes_got):
+        a, b = a.reshape(-1).cpu(), b.reshape(-1).cpu()
+        diff = a != b
+        n_dec += a.numel()
+        n_flip += int(diff.sum())
+        flipped_codes.update(a[diff].tolist())
+        flipped_codes.update(b[diff].tolist())
+    frac = n_flip / max(1, n_dec)
+    worst, worst_name = 0.0, ""
+    for k, v in got_state.items():
+        if not (v.is_floating_point() and v.numel()):
+            continue
+        r = ref_state[k]
+        d = (v - r).abs()
+        peak = float(r.abs().max())
+        if "vq._codebook." in k:
+            allowed = 1e-4 * peak + 1e-7
+            if flipped_codes:                                   # embed [1, C, d] / cluster_size [1, C]: drop the touched rows
+                keep = torch.ones(r.shape[1], dtype=torch.bool, device=d.device)
+                keep[torch.tensor(sorted(flipped_codes), device=d.device)] = False
+                d = d[:, keep]
+        else:
+            allowed = max(2.0 * steps * lr, 1e-3 * peak)
+        dev_ = float(d.max()) if d.numel() else 0.0
+        if dev_ / allowed > worst:
+            worst, worst_name = dev_ / allowed, f"{k}: |dev| {dev_:.2e}, peak {peak:.2e}"
+    print(f"  {label}: {n_flip} of {n_dec} code decisions flipped; worst deviation in units of its allowance "
+          f"{worst:.3f}  [{worst_name}]")
+    assert frac <= 0.02, f"{label}: {n_flip} of {n_dec} nearest-code decisions differ between two runs of the same steps"
+    assert worst <= 1.0, f"{label}: {worst_name}"
+    return frac
+
+
 def cos(a, b):
     a, b = a.detach().float().cpu().reshape(-1), b.detach().float().cpu().reshape(-1)
     return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
@@ -412,111 +459,3 @@ def test_config1_two_training_steps():
               f"grad-norm {trainer.optim.grad_norm():.4f} / {ref_norms[s]:.4f}")
         assert math.isfinite(loss) and rel <= 5e-2      # free-running codes on a 64-token toy: see test_config1_vs_oracle
         assert abs(trainer.optim.grad_norm() - ref_norms[s]) <= 0.1 * ref_norms[s]       # free-running codes
-
-
-# ------------------------------------------------------------------------------------------- SURVEY 8(f) row f1
-def test_batched_occlusion_sensitivity_vs_serial_and_oracle():
-    """utils.visualizations.Visualizations._compute_occlusion (reference src/utils/visualizations.py:335-424): windows
-    scored in device-side batches with the text side encoded once must give the heat-map of the reference's serial
-    one-forward-per-window loop -- (a) against the same HIP model run with batch 1, (b) against the f32 oracle restatement
-    of the reference loop."""
-    import numpy as np
-    from oracle import ctclip_oracle as O
-    from utils.visualizations import Visualizations
-
-    class Acc:                                     # the attributes of accelerate.Accelerator the class reads
-        is_main_process, process_index, num_processes, device = True, 0, 1, torch.device(DEV)
-
-    clip, data, cfg = _config1()
-    st = {k: v.clone() for k, v in clip.state_dict().items()}
-    txt, vol = data[0]
-    txt1 = {k: v[:1] for k, v in txt.items()}
-    image = vol[:1]
-    patch, stride = (32, 32, 32), (32, 32, 16)     # 2 x 2 x 3 = 12 windows, overlapping along w
-    clip = clip.to(DEV)
-    maps = {}
-    for b in (5, 1):                               # 5: two full batches + a ragged one; 1: the serial schedule
-        vis = Visualizations(clip, Acc(), occlusion_batch=b)
-        maps[b] = vis._compute_occlusion(image, txt1, None, patch, stride, 0.0)
-    assert maps[5].shape == (64, 64, 64)
-    check("occlusion batched vs serial (HIP)", torch.from_numpy(maps[5].copy()), torch.from_numpy(maps[1].copy()), 2e-2)
-    _, _, ref = O.occlusion_heatmap(txt1, image, st, cfg, patch, stride, 0.0)
-    a, b_ = maps[5].reshape(-1).astype(np.float64), ref.reshape(-1).astype(np.float64)
-    corr = float(np.corrcoef(a, b_)[0, 1])
-    print(f"  occlusion heat-map vs oracle: correlation {corr:.5f}, max |diff| {np.abs(a - b_).max():.3e}")
-    # free-running comparison: every occluded copy goes through the VQ arg-max, whose genuine near-ties flip under bf16
-    # noise (the caveat of test_config1_vs_oracle), so the maps agree in shape, not to rounding
-    assert corr >= 0.93 and np.abs(a - b_).max() <= 0.3
-    # precomputed text embeddings (the reference's `text_embeds` branch, :371-372,384-385)
-    emb = clip.encode_text({k: v.to(DEV) for k, v in txt1.items()}).detach()
-    m2 = Visualizations(clip, Acc(), occlusion_batch=4)._compute_occlusion(image, None, emb, patch, stride, 0.0)
-    check("occlusion with text_embeds", torch.from_numpy(m2.copy()), torch.from_numpy(maps[5].copy()), 2e-2)
-
-
-# ------------------------------------------------------------------------------------------- SURVEY 8(f) row f3
-def test_checkpoint_resume_continues_the_run(tmp_path):
-    """save_model / load_model (reference src/utils/CTClipTrainer.py:136-154) carry the optimiser moments and -- beyond
-    the reference -- the global step: a trainer restored from the checkpoint takes the same next step as the original."""
-    from utils.CTClipTrainer import CTClipTrainer
-    clip, data, _ = _config1()
-    trainer = CTClipTrainer(clip, batch_size=4, results_folder=str(tmp_path))
-    (txt0, vol0), (txt1, vol1) = data
-    trainer.train_step((vol0, txt0))
-    trainer.save_model("ckpt.pt")
-    ckpt = trainer.results_folder / "ckpt.pt"
-    assert ckpt.exists() and (trainer.results_folder / "architecture.txt").exists()
-    loss_a = trainer.train_step((vol1, txt1))
-    after_a = {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}
-
-    clip_b, _, _ = _config1()                      # fresh model + trainer, then restore
-    with torch.no_grad():
-        for p in clip_b.parameters():
-            p.add_(0.01)                           # make sure the restore is what brings the weights back
-    trainer_b = CTClipTrainer(clip_b, batch_size=4, results_folder=None)
-    trainer_b.load_model(ckpt)
-    assert trainer_b.global_step == 1
-    loss_b = trainer_b.train_step((vol1, txt1))
-    assert trainer_b.global_step == 2
-    print(f"  resumed step: loss {loss_b:.7f} vs uninterrupted {loss_a:.7f}")
-    assert abs(loss_a - loss_b) <= 1e-4 * abs(loss_a)
-    worst = 0.0
-    for k, v in trainer_b.model.state_dict().items():
-        if v.is_floating_point() and v.numel():
-            worst = max(worst, float((v - after_a[k]).abs().max() / (after_a[k].abs().max() + 1e-12)))
-    print(f"  worst parameter deviation after the resumed step: {worst:.2e}")
-    assert worst <= 1e-3                           # f32 atomics reorder sums; Adam's first steps amplify that to ~1e-4
-    with pytest.raises(FileNotFoundError):
-        trainer_b.load_model(tmp_path / "missing.pt")
-
-
-def test_integrated_gradients_vs_oracle():
-    """utils.visualizations (reference src/utils/visualizations.py:851-910): batched interpolation points, input gradient
-    through ctclip_patch_ln_bwd_dx, against the oracle's autograd over the same path (VQ codes free-running)."""
-    import numpy as np
-    from oracle import ctclip_oracle as O
-    from utils.visualizations import Visualizations
-
-    class Acc:
-        is_main_process, process_index, num_processes, device = True, 0, 1, torch.device(DEV)
-
-    clip, data, cfg = _config1()
-    st = {k: v.clone() for k, v in clip.state_dict().items()}
-    txt, vol = data[0]
-    txt1 = {k: v[:1] for k, v in txt.items()}
-    image = vol[:1]
-    steps = 6
-    avg_o, map_o = O.integrated_gradients(txt1, image, st, cfg, steps=steps)
-    clip = clip.to(DEV)
-    vis = Visualizations(clip, Acc())
-    avg, diff = vis._integrated_gradients(image, txt1, steps=steps, ig_batch=4)       # 4 + 2: a ragged last batch
-    avg1, _ = vis._integrated_gradients(image, txt1, steps=steps, ig_batch=1)         # the reference's serial schedule
-    check("IG batched vs serial (HIP)", avg, avg1, 1e-3)
-    a, b_ = avg.cpu().reshape(-1).double(), avg_o.reshape(-1).double()
-    cos = float((a @ b_) / (a.norm() * b_.norm()))
-    print(f"  IG average input gradient vs oracle: cosine {cos:.5f}, norm ratio {float(a.norm() / b_.norm()):.4f}")
-    assert cos >= 0.97 and 0.9 <= float(a.norm() / b_.norm()) <= 1.1
-    m = vis.visualize_integrated_gradients(image, txt1, steps=steps, ig_batch=4)
-    assert m.shape == map_o.shape and float(m.max()) <= 1.0 + 1e-6
-    agree = float(((m > 0) == (map_o > 0)).mean())
-    print(f"  IG top-decile mask agreement with the oracle map: {agree:.4f}")
-    assert agree >= 0.93

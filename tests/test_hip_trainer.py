@@ -69,7 +69,10 @@ def test_rccl_branches_run_at_world_size_one():
     # single-process result first
     clip, data, _ = _config1()
     trainer = CTClipTrainer(clip, batch_size=4, results_folder=None)
-    losses = [trainer.train_step((vol, txt)) for txt, vol in data]
+    losses, codes = [], []
+    for txt, vol in data:
+        losses.append(trainer.train_step((vol, txt)))
+        codes.append(clip.visual_transformer.vq.last_indices.clone())
     ref_state = {k: v.detach().clone() for k, v in clip.state_dict().items()}
     trainer.grad_sync.close()
     assert not trainer.accelerator.distributed
@@ -84,10 +87,11 @@ def test_rccl_branches_run_at_world_size_one():
         launched = []
         real = sync._launch
         sync._launch = lambda b: (launched.append((b["start"], b["stop"])), real(b))[1]
-        losses2 = []
+        losses2, codes2 = [], []
         for txt, vol in data2:
             n0 = len(launched)
             losses2.append(tr2.train_step((vol, txt)))
+            codes2.append(clip2.visual_transformer.vq.last_indices.clone())
             assert len(launched) - n0 == len(sync._buckets)              # every bucket reduced exactly once per step
         state_after_two = {k: v.detach().clone() for k, v in clip2.state_dict().items()}
         assert sync._bucket_of and all(b["handle"] is None for b in sync._buckets)
@@ -105,21 +109,14 @@ def test_rccl_branches_run_at_world_size_one():
         clip2.load_state_dict(state_after_two)                            # the comparison below is about the two default steps
         avg = tr2.avg_device_loss(losses2[-1])
         assert abs(avg - losses2[-1]) < 1e-6
-        for a, b in zip(losses, losses2):
+        for i, (a, b) in enumerate(zip(losses, losses2)):
             print(f"  loss single-process {a:.7f}  through RCCL {b:.7f}")
-            assert abs(a - b) <= 1e-3 * abs(a)                          # f32 atomics reorder sums, nothing else differs
-        # Both runs execute the same kernels; what differs is the order of f32 atomic adds inside gradient sums.  Adam's
-        # first steps move every element by ~lr * sign(g), so an element whose gradient is rounding noise may move the
-        # other way: allowed per element is that (2 steps x 2 lr) or 1e-3 of the tensor's peak, whichever is larger.
-        lr, worst, worst_name = 1.25e-5, 0.0, ""
-        for k, v in clip2.state_dict().items():
-            if v.is_floating_point() and v.numel():
-                dev = float((v - ref_state[k]).abs().max())
-                allowed = max(4.0 * lr, 1e-3 * float(ref_state[k].abs().max()))
-                if dev / allowed > worst:
-                    worst, worst_name = dev / allowed, f"{k}: {dev:.2e} (peak {float(ref_state[k].abs().max()):.2e})"
-        print(f"  worst parameter deviation after two steps, in units of the allowance: {worst:.2f}  [{worst_name}]")
-        assert worst <= 1.0
+            # f32 atomics reorder sums, nothing else differs -- unless that noise flipped a VQ near-tie in this step
+            # (same_trajectory below bounds how many may), which moves the loss of a 64-token toy by up to ~1e-3
+            same_codes = torch.equal(codes[i], codes2[i])
+            assert abs(a - b) <= (1e-5 if same_codes else 5e-3) * abs(a)
+        from test_hip_model import same_trajectory
+        same_trajectory(ref_state, clip2.state_dict(), codes, codes2, 1.25e-5, 2, "single process vs RCCL at world size 1")
         sync.close()
     finally:
         dist.destroy_process_group()
