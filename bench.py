@@ -119,12 +119,11 @@ def gemm_work_fns():
 def other_work_fns():
     """the kernels north_star names beside the GEMMs: tubelet patch-embed (HBM), spatial attention (MFMA), VQ search."""
     def patch_fwd(vol, is16, w, b, A, mean, rstd, B, C, Dz, Hy, Wx, tp, p, ldA, *rest):
+        # the gather + LayerNorm(4000) kernel ALONE: its algorithmic bytes are the volume read once; the normalised operand
+        # it writes ([tokens, 4000] bf16) is traffic the SURVEY 8(d) figure does not grant -- reported next to it
         M = B * (Dz // tp) * (Hy // p) * (Wx // p)
-        return {"tag": "patch_embed_fwd", "bytes": float(B * C * Dz * Hy * Wx * (2 if is16 else 4) + M * ldA * 2)}
-
-    def patch_bwd(vol, is16, dA, ldA, mean, rstd, dw, db, B, C, Dz, Hy, Wx, tp, p, *rest):
-        M = B * (Dz // tp) * (Hy // p) * (Wx // p)
-        return {"tag": "patch_embed_bwd", "bytes": float(B * C * Dz * Hy * Wx * (2 if is16 else 4) + M * ldA * 2)}
+        return {"tag": "tubelet_gather_ln_fwd", "bytes": float(B * C * Dz * Hy * Wx * (2 if is16 else 4)),
+                "operand_bytes_written": float(M * ldA * 2)}
 
     def attn_fwd(q, k, v, o, lse, bias, mask, nseq, n, heads, dp, *rest):
         if n < 256:
@@ -140,7 +139,94 @@ def other_work_fns():
 
     def vq(embed, x, pv, pi, ncodes, M, d, *rest):
         return {"tag": "vq_search", "flops": 2.0 * ncodes * M * d, "bytes": 2.0 * (M * d + ncodes * d) + 8.0 * 16 * M}
-    return {"patch_ln_fwd": patch_fwd, "patch_ln_bwd": patch_bwd, "attn_fwd": attn_fwd, "attn_bwd": attn_bwd, "vq_topk": vq}
+    return {"patch_ln_fwd": patch_fwd, "attn_fwd": attn_fwd, "attn_bwd": attn_bwd, "vq_topk": vq}
+
+
+def patch_embed_chain(model, vol, reps=5):
+    """SURVEY 8 row a1 / K1 as ONE unit (reference ctvit.py:44-52: Rearrange + LayerNorm(4000) + Linear(4000, 512) + LayerNorm(512)):
+    HIP events around the whole forward chain and around forward + backward, against SURVEY 8(d)'s algorithmic bytes
+    (volume + weight + 512-wide output = 128.9 MB per pair at bf16 input) -- NOT the bytes this implementation moves (it
+    materialises the normalised [tokens, 4000] operand; `roofline.kernels.tubelet_gather_ln_fwd` shows that kernel alone)."""
+    vit = model.visual_transformer
+    B, C, Dz, Hy, Wx = vol.shape
+    p, tp, dim = vit.patch_size, vit.temporal_patch_size, vit.to_patch_emb[2].weight.shape[0]
+    M = B * (Dz // tp) * (Hy // p) * (Wx // p)
+    F_ = C * tp * p * p
+    alg = float(vol.numel() * vol.element_size() + F_ * dim * 2 + M * dim * 2)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    with torch.no_grad():
+        vit.patch_embed(vol)
+    fwd, both = [], []
+    for _ in range(reps):
+        e0, e1 = ev(), ev()
+        with torch.no_grad():
+            e0.record(); vit.patch_embed(vol); e1.record()
+        torch.cuda.synchronize()
+        fwd.append(e0.elapsed_time(e1))
+    g = None
+    for _ in range(reps):
+        e0, e1 = ev(), ev()
+        e0.record()
+        y = vit.patch_embed(vol)
+        if g is None:
+            g = torch.ones_like(y)
+        y.backward(g)
+        e1.record()
+        torch.cuda.synchronize()
+        both.append(e0.elapsed_time(e1))
+    model.zero_grad(set_to_none=False)
+    f, fb = min(fwd), min(both)
+    gbps = alg / (f * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+            "ms_forward_chain": f, "ms_forward_plus_backward_chain": fb, "algorithmic_bytes_per_launch": alg,
+            "what": "whole K1 forward chain (gather + LN(4000) kernel, K = 4000 MFMA GEMM + folded bias, LN(512)) per call at this "
+                    "batch, best of %d, on SURVEY 8(d)'s bytes (volume + weight + 512-wide output); the chain is GEMM-bound: "
+                    "2 x tokens x 4000 x 512 flops = %.2f TFLOP" % (reps, 2.0 * M * F_ * dim / 1e12),
+            "mfma_tflops_of_the_chain": 2.0 * M * F_ * dim / (f * 1e-3) / 1e12}
+
+
+def attribution_bench(model, vol, txt, dev, windows=256, occlusion_batch=32, ig_steps=50, ig_batch=10):
+    """BASELINE configs[4] (reference src/utils/visualizations.py:335-424,851-910): batched occlusion sensitivity and
+    integrated gradients over ONE 480x480x240 volume on this GPU.  Occlusion: the first `windows` of the 12 167 windows of the
+    default (20,40,40)/(10,20,20) sweep, `occlusion_batch` per no-grad forward; IG: `ig_steps` interpolation points, forward +
+    backward to the volume.  Rate = CT-ViT forwards (or forward+backwards) per second; MFMA fraction on the SURVEY 8(a)
+    forward flops of the image tower (789.7 GF per volume)."""
+    from utils.visualizations import Visualizations
+
+    class Acc:
+        is_main_process, process_index, num_processes, device = True, 0, 1, dev
+    image = vol[:1]
+    txt1 = {k: v[:1] for k, v in txt.items()}
+    was = model.training
+    quiet = Visualizations(model, Acc(), occlusion_batch=occlusion_batch, max_windows=windows)
+    quiet.maybe_print = lambda *a, **k: None
+    quiet.max_windows = occlusion_batch                     # warm-up: one batch
+    quiet._compute_occlusion(image, txt1, None, (20, 40, 40), (10, 20, 20), 0.0)
+    quiet.max_windows = windows
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    quiet._compute_occlusion(image, txt1, None, (20, 40, 40), (10, 20, 20), 0.0)
+    torch.cuda.synchronize()
+    occ_s = time.perf_counter() - t0
+    quiet._integrated_gradients(image, txt1, steps=ig_batch, ig_batch=ig_batch)      # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    quiet._integrated_gradients(image, txt1, steps=ig_steps, ig_batch=ig_batch)
+    torch.cuda.synchronize()
+    ig_s = time.perf_counter() - t0
+    model.train(was)
+    model.zero_grad(set_to_none=False)
+    fwd_gf = 789.7e9
+    occ_rate = (windows + 1) / occ_s
+    return {"workload": "BASELINE configs[4]: one 480x480x240 bf16 volume, 128-token report, production CT-CLIP",
+            "occlusion": {"windows": windows, "batch": occlusion_batch, "seconds": occ_s, "value": occ_rate, "unit": "windows/s",
+                          "full_sweep_12167_windows_s": 12167.0 / occ_rate,
+                          "reference_notebook_rate": "about 10 forwards/s on an unnamed GPU (SURVEY section 6)",
+                          "roofline": {"bound": "mfma", "achieved": occ_rate * fwd_gf / 1e12, "peak": PEAK_BF16_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": occ_rate * fwd_gf / 1e12 / PEAK_BF16_TFLOPS}},
+            "integrated_gradients": {"steps": ig_steps, "batch": ig_batch, "seconds": ig_s, "value": ig_steps / ig_s,
+                                     "unit": "points/s (forward + backward to the volume)"}}
+
 
 
 def measured_peaks(hip, dev):
@@ -179,12 +265,13 @@ def cpu_baseline(model, depth, size, L, vocab, reps=3):
     optimisation target."""
     import statistics
     from oracle import ctclip_oracle as O
-    # the GPU box grants a 16-core share of a much larger host: size the pool to the share, not to os.cpu_count()
+    # BASELINE.md section 2: torch.set_num_threads(os.cpu_count()) -- here the cores this process may actually run on (its
+    # affinity mask: 256 on the driver's box, 16 on a shared one), stated in the result
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(16, avail))
+    cores = max(1, avail)
     torch.set_num_threads(cores)
     log = lambda m: print(f"[cpu_baseline] {m}", file=sys.stderr, flush=True)
     log(f"{cores} threads (affinity {avail}, os.cpu_count {os.cpu_count()})")
@@ -310,6 +397,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("CTCLIP_BENCH_BATCH", 64)), help="pairs per GPU")
     ap.add_argument("--text-len", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-attribution", action="store_true", help="skip the BASELINE configs[4] measurement (occlusion + IG)")
     ap.add_argument("--local-negatives", action="store_true", help="BASELINE config 3: no embedding all-gather")
     ap.add_argument("--small", action="store_true", help="debug: 2+2-layer model on 64^3 volumes")
     args = ap.parse_args()
@@ -388,6 +476,13 @@ def main():
     timed2 = hip.stop_timing()
     alone = family(timed2)
     _ops._side["on"] = side_was
+    # what the HIP-event pairs around the GEMM launches cost the timed region: the same steps once more with no timing armed
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(batch)
+    sync()
+    dt_plain = time.perf_counter() - t1
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -403,21 +498,24 @@ def main():
         alone_tflops = alone["flops"] / (alone["total_ms"] * 1e-3) / 1e12 if alone["total_ms"] > 0 else 0.0
         kernels = {}
         tags = {}
-        for n in ("ctclip_patch_ln_fwd", "ctclip_patch_ln_bwd", "ctclip_attn_fwd", "ctclip_attn_bwd", "ctclip_vq_topk"):
+        for n in ("ctclip_patch_ln_fwd", "ctclip_attn_fwd", "ctclip_attn_bwd", "ctclip_vq_topk"):
             for ms, w in timed2.get(n, {}).get("items", []):
-                d = tags.setdefault(w["tag"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+                d = tags.setdefault(w["tag"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "extra_written": 0.0})
                 d["ms"] += ms; d["flops"] += w.get("flops", 0.0); d["bytes"] += w["bytes"]; d["launches"] += 1
-        pmc_names = {"patch_embed_fwd": ("patch_ln_fwd_fast",), "patch_embed_bwd": ("patch_ln_bwd_fast",),
+                d["extra_written"] += w.get("operand_bytes_written", 0.0)
+        pmc_names = {"tubelet_gather_ln_fwd": ("patch_ln_fwd_fast",),
                      "spatial_attention_fwd": ("ws_fwd_kernel",), "vq_search": ("vq_topk3_kernel",),
                      "spatial_attention_bwd": ("ws_bwd_dq_kernel", "ws_bwd_dkv_kernel")}
         for tag, d in tags.items():
             if d["ms"] <= 0:
                 continue
             ent = {"launches_per_step": d["launches"] / extra, "ms_per_step": d["ms"] / extra}
-            if tag.startswith("patch_embed"):
+            if tag.startswith("tubelet"):
                 gbps = d["bytes"] / (d["ms"] * 1e-3) / 1e9
                 ent.update(bound="hbm", achieved=gbps, peak=PEAK_HBM_GBPS, unit="GB/s", frac=gbps / PEAK_HBM_GBPS,
-                           frac_of_measured_copy=gbps / peaks["hbm_copy_gbps"], algorithmic_bytes_per_launch=d["bytes"] / d["launches"])
+                           frac_of_measured_copy=gbps / peaks["hbm_copy_gbps"], algorithmic_bytes_per_launch=d["bytes"] / d["launches"],
+                           operand_bytes_written_per_launch=d["extra_written"] / d["launches"],
+                           achieved_incl_operand_write=(d["bytes"] + d["extra_written"]) / (d["ms"] * 1e-3) / 1e9)
             else:
                 tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 ent.update(bound="mfma", achieved=tf, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_BF16_TFLOPS,
@@ -425,6 +523,8 @@ def main():
             hits = [[v for k, v in per_kernel_traffic.items() if k.startswith(pref)] for pref in pmc_names.get(tag, ())]
             ent["traffic"] = sum(h[0] for h in hits) if hits and all(hits) else None      # a call = one launch of each kernel named
             kernels[tag] = ent
+        if world == 1:
+            kernels["patch_embed_fwd"] = patch_embed_chain(model, vol)
         # the whole step against HBM: counter traffic of every kernel of one step (same committed PMC passes) / the copy rate this
         # box sustains -- the step moves ~1.1 TB, so this, not the MFMA peak, is the bound the step as a whole runs against
         step_hbm = None
@@ -470,10 +570,19 @@ def main():
                          "frac_of_measured_mfma_without_stream_overlap": alone_tflops / peaks["mfma_bf16_tflops"],
                          "kernels": kernels,
                          "side_stream": bool(side_was),
+                         "event_timing": {"ms_per_step_with_event_pairs": 1e3 * dt / args.steps,
+                                          "ms_per_step_without": 1e3 * dt_plain / args.steps,
+                                          "overhead_frac": (dt - dt_plain) / dt_plain,
+                                          "what": "the timed region records a HIP-event pair around each of the step's ~294 GEMM "
+                                                  "launches; the same steps re-run with nothing armed show what that costs"},
                          "note": "achieved: HIP-event durations inside the timed region (single stream unless CTCLIP_WGRAD_STREAM=1 "
                                  "puts the weight-gradient GEMMs on a second one); *_without_stream_overlap and `kernels`: same "
                                  "launches, two extra untimed steps on one stream; flops counted on the unpadded GEGLU width 1365"},
         }
+        if not args.no_attribution and world == 1 and not args.small:
+            del batch
+            torch.cuda.empty_cache()
+            out["attribution"] = attribution_bench(model, vol, txt, dev)
         if not args.no_cpu_baseline and world == 1 and not args.small:
             out["cpu_baseline"] = cpu_baseline(model, depth, size, args.text_len, text_cfg["vocab_size"])
         print(json.dumps(out), flush=True)

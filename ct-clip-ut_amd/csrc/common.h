@@ -25,6 +25,12 @@ typedef __attribute__((ext_vector_type(8))) short short8v;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// Scratch every entry point with a `partials` argument may use: CTCLIP_PARTIALS_FLOATS of include/ctclip_hip.h.
+constexpr long kPartialsFloats = 1L << 21;
+// out[c] += sum_{part < nparts, in index order} partials[part * ld + c]  (tail.hip; the second stage of the two-stage
+// reductions: no atomics, bitwise reproducible)
+int ctclip_reduce_partials(const float* partials, int nparts, long ld, int width, float* out, hipStream_t st);
+
 #define CTCLIP_CHECK_LAUNCH() \
   do {                        \
     hipError_t e_ = hipGetLastError(); \
@@ -62,8 +68,9 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 // The GELUs inside the GEMM epilogues (GEGLU forward / backward: 64-128 evaluations per lane and tile, VALU time the matrix
 // pipe waits for) use a transcendental-free form: Phi(x) - 1/2 = x Q(x^2), Q a degree-6 minimax polynomial on |x| <= 3.7
-// (x clamped there: Phi stays inside [5.9e-5, 1 - 5.9e-5]).  |Phi error| <= 6e-5, |gelu error| <= 6e-5 |x| -- a thirtieth of
-// the bf16 rounding of the values these epilogues store; 10 issue slots against ~19 with two quarter-rate instructions.
+// (beyond it Phi is exactly 0 / 1, so gelu(x) = 0 for x < -3.7 and x for x > 3.7).  |Phi error| <= 6e-5 inside the range and
+// <= 1.1e-4 at the jump, |gelu error| <= 4e-4 absolute and <= 1.1e-4 |x| -- a thirtieth of the bf16 rounding of the values
+// these epilogues store; 13 issue slots against ~19 with two quarter-rate instructions.
 __device__ __forceinline__ float norm_cdf_fast(float x) {
   const float xc = __builtin_amdgcn_fmed3f(x, -3.7f, 3.7f);
   const float w = xc * xc;
@@ -73,7 +80,9 @@ __device__ __forceinline__ float norm_cdf_fast(float x) {
   q = fmaf(q, w, 9.406451136e-03f);
   q = fmaf(q, w, -6.585516781e-02f);
   q = fmaf(q, w, 3.987334669e-01f);
-  return fmaf(xc, q, 0.5f);
+  // outside the fitted range Phi saturates to exactly 0 / 1 (x - xc is 0 inside it, and of x's sign beyond): without this
+  // gelu(x) would leak 5.9e-5 |x| for strongly negative x
+  return __builtin_amdgcn_fmed3f(fmaf(x - xc, 1e30f, fmaf(xc, q, 0.5f)), 0.f, 1.f);
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) { return x * norm_cdf_fast(x); }
 // d/dx [x Phi(x)] = Phi(x) + x phi(x)

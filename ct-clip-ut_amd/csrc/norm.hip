@@ -1,7 +1,9 @@
 // LayerNorm (with / without bias) and per-head cosine normalisation, forward + backward.
 // All HBM-bound: one wave per row, float4 / 16-byte accesses, rows kept in registers between the
-// statistics pass and the normalise pass (dim <= 4096), column reductions (dgamma, dbeta, dscale)
-// accumulated per wave across a grid-stride loop and flushed with one f32 atomic per column.
+// statistics pass and the normalise pass (dim <= 4096).  Column reductions (dgamma, dbeta, dscale) are accumulated per
+// wave across a grid-stride loop, combined over the workgroup's waves in a fixed order and stored as one row of
+// `partials` per workgroup; ctclip_reduce_partials (tail.hip) adds the rows up in index order.  No atomics: the same
+// inputs give the same bits.
 #include "common.h"
 
 namespace {
@@ -92,15 +94,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             const bf16_t* __restrict__ dres2,
                                                             float* __restrict__ dx, bf16_t* __restrict__ dx16,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ partials, int want_beta,
                                                             int rows, int dim, int swap_a, int swap_c) {
-  extern __shared__ __attribute__((aligned(16))) float lnred[];   // [2][dim]
+  extern __shared__ __attribute__((aligned(16))) float lnred[];   // [4 waves][2][dim]
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
   const int nv = dim >> 2;
-  for (int i = threadIdx.x; i < 2 * dim; i += 256) lnred[i] = 0.f;
-  __syncthreads();
   float4 ag[LN_NV], ab[LN_NV];
 #pragma unroll
   for (int i = 0; i < LN_NV; ++i) {
@@ -163,21 +163,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
       }
     }
   }
+  float* mine = lnred + (threadIdx.x >> 6) * 2 * dim;                // this wave's [gamma | beta] row
 #pragma unroll
   for (int i = 0; i < LN_NV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
-      float* pg = lnred + c * 4;
-      atomicAdd(pg + 0, ag[i].x); atomicAdd(pg + 1, ag[i].y); atomicAdd(pg + 2, ag[i].z); atomicAdd(pg + 3, ag[i].w);
-      float* pb = lnred + dim + c * 4;
-      atomicAdd(pb + 0, ab[i].x); atomicAdd(pb + 1, ab[i].y); atomicAdd(pb + 2, ab[i].z); atomicAdd(pb + 3, ab[i].w);
+      ((float4*)mine)[c] = ag[i];
+      ((float4*)(mine + dim))[c] = ab[i];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < dim; i += 256) {
-    atomicAdd(dgamma + i, lnred[i]);
-    if (dbeta) atomicAdd(dbeta + i, lnred[dim + i]);
-  }
+  const int width = want_beta ? 2 * dim : dim;
+  float* prow = partials + (long)blockIdx.x * width;                 // [dgamma (dim) | dbeta (dim)]
+  for (int i = threadIdx.x; i < width; i += 256)
+    prow[i] = (lnred[i] + lnred[2 * dim + i]) + (lnred[4 * dim + i] + lnred[6 * dim + i]);
 }
 
 // ---- per-head cosine normalisation: y = x / max(|x|,1e-12) * scale[d] * mult --------------------
@@ -224,12 +223,10 @@ __global__ __launch_bounds__(256) void headnorm_fwd_kernel(const bf16_t* __restr
 template <int LPH>
 __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                            const float* __restrict__ inv_norm, const float* __restrict__ scale,
-                                                           bf16_t* __restrict__ dx, float* __restrict__ dscale,
+                                                           bf16_t* __restrict__ dx, float* __restrict__ partials,
                                                            long npairs, int H, long lddy, long ldx, long lddx, float mult) {
-  __shared__ float red[LPH * 8];
+  __shared__ float red[256 / LPH][LPH * 8 + 1];                      // [pair slot of the workgroup][d]
   const int D = LPH * 8;
-  if (threadIdx.x < D) red[threadIdx.x] = 0.f;
-  __syncthreads();
   const int sub = threadIdx.x % LPH;
   float acc[8];
 #pragma unroll
@@ -272,12 +269,55 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restr
     }
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) atomicAdd(&red[sub * 8 + i], acc[i]);
+  for (int i = 0; i < 8; ++i) red[threadIdx.x / LPH][sub * 8 + i] = acc[i];
   __syncthreads();
-  if (threadIdx.x < D) atomicAdd(&dscale[threadIdx.x], red[threadIdx.x]);
+  if (threadIdx.x < D) {                                             // the workgroup's pair slots in slot order
+    float s = 0.f;
+    for (int g = 0; g < 256 / LPH; ++g) s += red[g][threadIdx.x];
+    partials[(long)blockIdx.x * D + threadIdx.x] = s;
+  }
 }
 
 }  // namespace
+
+// workgroups of the LayerNorm backward: every wave at least 8 rows (the partial rows are summed by a second kernel whose
+// time grows with their number), at most 1024, and never more partial rows than the scratch holds
+static int ln_bwd_blocks(int rows, int dim) {
+  long blocks = (rows + 31) / 32;
+  if (blocks > 1024) blocks = 1024;
+  const long fit = kPartialsFloats / (2L * dim);
+  if (blocks > fit) blocks = fit;
+  return blocks < 1 ? 1 : (int)blocks;
+}
+
+// second stage: d(gamma) and, if asked for, d(beta) from the [blocks][width] partial rows
+static int ln_bwd_finish(const float* partials, int blocks, int dim, float* dgamma, float* dbeta, hipStream_t st) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  const int width = dbeta ? 2 * dim : dim;
+  int r = ctclip_reduce_partials(partials, blocks, width, dim, dgamma, st);
+  if (r == 0 && dbeta) r = ctclip_reduce_partials(partials + dim, blocks, width, dim, dbeta, st);
+  return r;
+}
+
+template <bool DY16>
+static int ln_bwd_launch(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                         const float* dres, const bf16_t* dres2, float* dx, bf16_t* dx16, float* dgamma, float* dbeta,
+                         float* partials, int rows, int dim, int A, int C, hipStream_t st) {
+  if (!partials || !dgamma) return (int)hipErrorInvalidValue;
+  const int blocks = ln_bwd_blocks(rows, dim);
+  const size_t lnlds = (size_t)8 * dim * sizeof(float);
+#define LN_BWD(NV)                                                                                                       \
+  do {                                                                                                                   \
+    if (lnlds > 65536) hipFuncSetAttribute((const void*)layernorm_bwd_kernel<NV, DY16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lnlds); \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<NV, DY16>), dim3(blocks), dim3(256), lnlds, st, dy, x, gamma, mean, rstd, dres, \
+                       dres2, dx, dx16, partials, dbeta ? 1 : 0, rows, dim, A, C);                                       \
+  } while (0)
+  const int nv = (dim / 4 + 63) / 64;
+  if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(16);
+#undef LN_BWD
+  return ln_bwd_finish(partials, blocks, dim, dgamma, dbeta, st);
+}
 
 extern "C" {
 
@@ -296,19 +336,11 @@ int ctclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 
 int ctclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                          const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int rows, int dim,
-                         void* stream) {
+                         float* partials, void* stream) {
   if (rows <= 0) return 0;
   if ((dim & 3) || dim > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
-  int blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
-  const size_t lnlds = (size_t)2 * dim * sizeof(float);
-#define LN_BWD(NV)                                                                                                      \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<NV, false>), dim3(blocks), dim3(256), lnlds, (hipStream_t)stream, (const void*)dy, x, \
-                     gamma, mean, rstd, dres, (const bf16_t*)nullptr, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim, 0, 0)
-  const int nv = (dim / 4 + 63) / 64;
-  if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(16);
-#undef LN_BWD
-  CTCLIP_CHECK_LAUNCH();
+  return ln_bwd_launch<false>(dy, x, gamma, mean, rstd, dres, nullptr, dx, (bf16_t*)dx_bf16, dgamma, dbeta, partials, rows,
+                              dim, 0, 0, (hipStream_t)stream);
 }
 
 int ctclip_layernorm_swap_fwd(const float* x, const float* gamma, const float* beta, float* y_f32, float* mean, float* rstd,
@@ -326,37 +358,20 @@ int ctclip_layernorm_swap_fwd(const float* x, const float* gamma, const float* b
 
 int ctclip_layernorm_swap_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                               float* dx, void* dx_bf16, float* dgamma, float* dbeta, int rows, int dim, int A, int C,
-                              void* stream) {
+                              float* partials, void* stream) {
   if (rows <= 0) return 0;
   if ((dim & 3) || dim > 64 * 4 * LN_MAXV || A <= 0 || C <= 0 || rows % (A * C)) return (int)hipErrorInvalidValue;
-  int blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
-  const size_t lnlds = (size_t)2 * dim * sizeof(float);
-#define LN_BWD(NV)                                                                                                      \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<NV, false>), dim3(blocks), dim3(256), lnlds, (hipStream_t)stream, (const void*)dy, x, \
-                     gamma, mean, rstd, (const float*)nullptr, (const bf16_t*)nullptr, dx, (bf16_t*)dx_bf16, dgamma, dbeta,   \
-                     rows, dim, A, C)
-  const int nv = (dim / 4 + 63) / 64;
-  if (nv <= 1) LN_BWD(1); else if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 4) LN_BWD(4); else LN_BWD(16);
-#undef LN_BWD
-  CTCLIP_CHECK_LAUNCH();
+  return ln_bwd_launch<false>(dy, x, gamma, mean, rstd, nullptr, nullptr, dx, (bf16_t*)dx_bf16, dgamma, dbeta, partials, rows,
+                              dim, A, C, (hipStream_t)stream);
 }
 
 int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* dres, const void* dres2_bf16, float* dx, void* dx_bf16, float* dgamma,
-                              float* dbeta, int rows, int dim, void* stream) {
+                              float* dbeta, int rows, int dim, float* partials, void* stream) {
   if (rows <= 0) return 0;
   if ((dim & 3) || dim > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
-  int blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
-  const size_t lnlds = (size_t)2 * dim * sizeof(float);
-#define LN_BWD16(NV)                                                                                                    \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<NV, true>), dim3(blocks), dim3(256), lnlds, (hipStream_t)stream, dy_bf16, x, gamma, \
-                     mean, rstd, dres, (const bf16_t*)dres2_bf16, dx, (bf16_t*)dx_bf16, dgamma, dbeta, rows, dim, 0, 0)
-  const int nv = (dim / 4 + 63) / 64;
-  if (nv <= 1) LN_BWD16(1); else if (nv <= 2) LN_BWD16(2); else if (nv <= 3) LN_BWD16(3); else if (nv <= 4) LN_BWD16(4); else LN_BWD16(16);
-#undef LN_BWD16
-  CTCLIP_CHECK_LAUNCH();
+  return ln_bwd_launch<true>(dy_bf16, x, gamma, mean, rstd, dres, (const bf16_t*)dres2_bf16, dx, (bf16_t*)dx_bf16, dgamma,
+                             dbeta, partials, rows, dim, 0, 0, (hipStream_t)stream);
 }
 
 int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_norm, long rows, int heads, int dhead,
@@ -378,21 +393,23 @@ int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_n
 
 int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
                         float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
-                        void* stream) {
+                        float* partials, void* stream) {
   const long npairs = rows * heads;
   if (npairs <= 0) return 0;
-  if (dhead != 32 && dhead != 64) return (int)hipErrorInvalidValue;
+  if ((dhead != 32 && dhead != 64) || !partials) return (int)hipErrorInvalidValue;
   const int lph = dhead / 8;
   long blocks = (npairs + (256 / lph) - 1) / (256 / lph);
   if (blocks > 2048) blocks = 2048;
   dim3 grid((unsigned)blocks), block(256);
   if (lph == 4)
     hipLaunchKernelGGL(headnorm_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
-                       inv_norm, scale, (bf16_t*)dx, dscale, npairs, heads, lddy, ldx, lddx, mult);
+                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult);
   else
     hipLaunchKernelGGL(headnorm_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
-                       inv_norm, scale, (bf16_t*)dx, dscale, npairs, heads, lddy, ldx, lddx, mult);
-  CTCLIP_CHECK_LAUNCH();
+                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return ctclip_reduce_partials(partials, (int)blocks, dhead, dhead, dscale, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -91,38 +91,6 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const TIN* __restrict
   }
 }
 
-// dgamma[f] += sum_tokens dA[token][f] * xhat ; dbeta[f] += sum_tokens dA[token][f]
-template <typename TIN>
-__global__ __launch_bounds__(256) void patch_ln_bwd_kernel(const TIN* __restrict__ vol, const bf16_t* __restrict__ dA,
-                                                           long ldd, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, PatchGeom g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  TIN* buf = (TIN*)smem;
-  const int tid = threadIdx.x;
-  int bid = blockIdx.x;
-  const int wg = bid % g.wgroups; bid /= g.wgroups;
-  const int h = bid % g.Ht; bid /= g.Ht;
-  const int t = bid % g.Tt;
-  const int b = bid / g.Tt;
-  const int w0 = wg * g.tpb;
-  const int ntok = min(g.tpb, g.Wt - w0);
-  gather_block<TIN>(buf, vol, g, b, t, h, w0, ntok, tid);
-  __syncthreads();
-  const long row0 = (((long)b * g.Tt + t) * g.Ht + h) * g.Wt + w0;
-  for (int f = tid; f < g.F; f += 256) {
-    float ag = 0.f, ab = 0.f;
-    for (int tok = 0; tok < ntok; ++tok) {
-      const float d = bf16_to_f32(dA[(row0 + tok) * ldd + f]);
-      const float xh = (ldf<TIN>(buf[tok * g.F + f]) - mean[row0 + tok]) * rstd[row0 + tok];
-      ag += d * xh;
-      ab += d;
-    }
-    atomicAdd(dgamma + f, ag);
-    atomicAdd(dbeta + f, ab);
-  }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // Fast path (the production geometry: p even, rows of tpb*p voxels a whole number of 16-byte vectors):
 //   phase 1  16-byte coalesced global loads straight into an LDS image kept in VOLUME order  buf[c*pt*p1 row][tpb*p2]
@@ -239,55 +207,63 @@ __global__ __launch_bounds__(PF_THREADS) void patch_ln_fwd_fast(const TIN* __res
   }
 }
 
-// dgamma / dbeta of the first LayerNorm.  A workgroup walks `hgroup` consecutive (b,t,h) slabs (both w halves of each),
-// every thread owning fixed feature pairs, so the atomics are issued once per workgroup instead of once per slab.
-template <typename TIN>
-__global__ __launch_bounds__(PF_THREADS) void patch_ln_bwd_fast(const TIN* __restrict__ vol, const bf16_t* __restrict__ dA, long ldd,
-                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+// ------------------------------------------------------------------------------------------------------------------
+// The affine part of LayerNorm(F) folded into the tubelet projection (reference ctvit.py:49-50):
+//     z = (xhat * gamma + beta) W^T + b  =  xhat (W * gamma)^T + (b + W beta),      xhat = (x - mean) * rstd
+// so the GEMM operand is the plain normalised tubelet row and NOTHING of the 4000-wide backward has to be materialised:
+// with G = dz^T xhat (the one weight-gradient GEMM, [N, F] f32) and db = colsum(dz),
+//     dW[n][f]  = G[n][f] gamma[f] + db[n] beta[f]
+//     dgamma[f] = sum_n W[n][f] G[n][f]            dbeta[f] = sum_n W[n][f] db[n]
+// exactly (no division by gamma).  The data-gradient GEMM dz W [tokens, F] and the pass over it that the unfolded form needs
+// for d(gamma) / d(beta) (3.6 TFLOP and 2 x 7 GB at 64 pairs) are gone.
+// fold: one workgroup per output row n
+__global__ __launch_bounds__(256) void patch_affine_fold_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                bf16_t* __restrict__ Wg, float* __restrict__ bfold, int F, long ldw) {
+  __shared__ float wsum[4];
+  const int n = blockIdx.x;
+  float s = 0.f;
+  for (int f = threadIdx.x; f < (int)ldw; f += 256) {
+    float w = 0.f;
+    if (f < F) {
+      w = W[(long)n * F + f];
+      s = fmaf(w, beta[f], s);
+      w *= gamma[f];
+    }
+    Wg[(long)n * ldw + f] = f32_to_bf16(w);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bfold[n] = (bias ? bias[n] : 0.f) + ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+}
+
+// backward: a workgroup owns 64 features, its four row lanes split the N output rows (combined in a fixed order)
+__global__ __launch_bounds__(256) void patch_affine_bwd_kernel(const float* __restrict__ G, const float* __restrict__ db,
+                                                               const float* __restrict__ W, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ dW,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               PatchGeom g, int hgroup) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nrows = g.C * g.pt * g.p, rlb = g.tpb * g.p * (int)sizeof(TIN);
-  char* buf = smem;
-  const int tid = threadIdx.x;
-  constexpr int MAXP = 4;                                               // feature pairs per thread: F <= 2*4*512 = 4096
-  float ag[MAXP][2], ab[MAXP][2];
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i) { ag[i][0] = ag[i][1] = ab[i][0] = ab[i][1] = 0.f; }
-  const long slab0 = (long)blockIdx.x * hgroup;
-  const long nslabs = (long)g.B * g.Tt * g.Ht;
-  for (long sl = slab0; sl < slab0 + hgroup && sl < nslabs; ++sl) {
-    const int h = (int)(sl % g.Ht);
-    const int t = (int)((sl / g.Ht) % g.Tt);
-    const int b = (int)(sl / ((long)g.Ht * g.Tt));
-    for (int wg = 0; wg < g.wgroups; ++wg) {
-      const int w0 = wg * g.tpb;
-      __syncthreads();
-      load_block_vec<TIN>(buf, vol, g, b, t, h, w0, tid);
-      __syncthreads();
-      const long row0 = (((long)b * g.Tt + t) * g.Ht + h) * g.Wt + w0;
-#pragma unroll
-      for (int i = 0; i < MAXP; ++i) {
-        const int f = (i * PF_THREADS + tid) * 2;
-        if (f >= g.F) continue;
-        const int rowid = fdiv(f, g.m_p), c2 = f - rowid * g.p;
-        for (int tok = 0; tok < g.tpb; ++tok) {
-          const uint32_t dw = *(const uint32_t*)(dA + (row0 + tok) * ldd + f);
-          const float d0 = __uint_as_float(dw << 16), d1 = __uint_as_float(dw & 0xffff0000u);
-          const float mu = mean[row0 + tok], rs = rstd[row0 + tok];
-          const float2 v = ld_pair<TIN>(buf, rlb, rowid, tok * g.p + c2);
-          ag[i][0] += d0 * (v.x - mu) * rs; ag[i][1] += d1 * (v.y - mu) * rs;
-          ab[i][0] += d0; ab[i][1] += d1;
-        }
-      }
+                                                               int N, int F) {
+  __shared__ float red[2][4][64];
+  const int fl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + fl;
+  float ag = 0.f, ab = 0.f;
+  if (f < F) {
+    const float gm = gamma[f], bt = beta[f];
+    for (int n = rl; n < N; n += 4) {
+      const long e = (long)n * F + f;
+      const float g = G[e], w = W[e], d = db[n];
+      ag = fmaf(w, g, ag);
+      ab = fmaf(w, d, ab);
+      dW[e] += fmaf(g, gm, d * bt);
     }
   }
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    const int f = (i * PF_THREADS + tid) * 2;
-    if (f >= g.F) continue;
-    atomicAdd(dgamma + f, ag[i][0]); atomicAdd(dgamma + f + 1, ag[i][1]);
-    atomicAdd(dbeta + f, ab[i][0]); atomicAdd(dbeta + f + 1, ab[i][1]);
+  red[0][rl][fl] = ag;
+  red[1][rl][fl] = ab;
+  __syncthreads();
+  if (rl == 0 && f < F) {
+    dgamma[f] += (red[0][0][fl] + red[0][1][fl]) + (red[0][2][fl] + red[0][3][fl]);
+    dbeta[f] += (red[1][0][fl] + red[1][1][fl]) + (red[1][2][fl] + red[1][3][fl]);
   }
 }
 
@@ -421,42 +397,20 @@ int ctclip_patch_ln_fwd(const void* volume, int volume_is_bf16, const float* gam
   CTCLIP_CHECK_LAUNCH();
 }
 
-int ctclip_patch_ln_bwd(const void* volume, int volume_is_bf16, const void* dA_bf16, long ldd, const float* mean,
-                        const float* rstd, float* dgamma, float* dbeta, int B, int C, int Dz, int Hy, int Wx, int pt,
-                        int p, void* stream) {
-  PatchGeom g{};
-  size_t lds = 0;
-  const long F = (long)C * pt * p * p;
-  if (int e = make_geom(g, B, C, Dz, Hy, Wx, pt, p, (F + 7) / 8 * 8, 0.f, volume_is_bf16, &lds)) return e;
-  {
-    PatchGeom gf = g;
-    size_t ldsf = 0;
-    if (fast_geom(gf, volume, volume_is_bf16 ? 2 : 4, &ldsf) && (ldd & 1) == 0 && (((uintptr_t)dA_bf16) & 3) == 0) {
-      const int hgroup = 4;
-      const long nslabs = (long)B * gf.Tt * gf.Ht;
-      const unsigned nb = (unsigned)((nslabs + hgroup - 1) / hgroup);
-      if (volume_is_bf16) {
-        if (ldsf > 65536) hipFuncSetAttribute((const void*)patch_ln_bwd_fast<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
-        hipLaunchKernelGGL(patch_ln_bwd_fast<bf16_t>, dim3(nb), dim3(PF_THREADS), ldsf, (hipStream_t)stream,
-                           (const bf16_t*)volume, (const bf16_t*)dA_bf16, ldd, mean, rstd, dgamma, dbeta, gf, hgroup);
-      } else {
-        if (ldsf > 65536) hipFuncSetAttribute((const void*)patch_ln_bwd_fast<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
-        hipLaunchKernelGGL(patch_ln_bwd_fast<float>, dim3(nb), dim3(PF_THREADS), ldsf, (hipStream_t)stream,
-                           (const float*)volume, (const bf16_t*)dA_bf16, ldd, mean, rstd, dgamma, dbeta, gf, hgroup);
-      }
-      CTCLIP_CHECK_LAUNCH();
-    }
-  }
-  const unsigned nblk = (unsigned)((long)B * g.Tt * g.Ht * g.wgroups);
-  if (volume_is_bf16) {
-    if (lds > 65536) hipFuncSetAttribute((const void*)patch_ln_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(patch_ln_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)volume,
-                       (const bf16_t*)dA_bf16, ldd, mean, rstd, dgamma, dbeta, g);
-  } else {
-    if (lds > 65536) hipFuncSetAttribute((const void*)patch_ln_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(patch_ln_bwd_kernel<float>, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const float*)volume,
-                       (const bf16_t*)dA_bf16, ldd, mean, rstd, dgamma, dbeta, g);
-  }
+int ctclip_patch_affine_fold(const float* W, const float* bias, const float* gamma, const float* beta, void* Wg_bf16,
+                             float* bias_folded, int N, int F, long ldw, void* stream) {
+  if (N <= 0 || F <= 0) return 0;
+  if (ldw < F) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(patch_affine_fold_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, W, bias, gamma, beta,
+                     (bf16_t*)Wg_bf16, bias_folded, F, ldw);
+  CTCLIP_CHECK_LAUNCH();
+}
+
+int ctclip_patch_affine_bwd(const float* G, const float* db, const float* W, const float* gamma, const float* beta, float* dW,
+                            float* dgamma, float* dbeta, int N, int F, void* stream) {
+  if (N <= 0 || F <= 0) return 0;
+  hipLaunchKernelGGL(patch_affine_bwd_kernel, dim3((F + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, db, W, gamma, beta,
+                     dW, dgamma, dbeta, N, F);
   CTCLIP_CHECK_LAUNCH();
 }
 

@@ -111,16 +111,18 @@ __global__ __launch_bounds__(256) void peg_sweep_kernel(const float* __restrict_
 
 // dw27[kt,kh,kw][c] += sum dy[t,h,w][c] * x[t+kt-2, h+kh-1, w+kw-1][c];  dbias[c] += sum dy.
 // Same sweep over t: a thread keeps the dy rows of three consecutive output times in registers, loads each x row once and
-// feeds all 9 (kt,kw) taps of that kh from it; the 27+1 float4 accumulators are flushed with atomics at the end.
+// feeds all 9 (kt,kw) taps of that kh from it; the 27+1 float4 accumulators of a (b, h, w chunk) group are stored as one row
+// [28][d] of `partials` (groups group0 .. group0 + ngroups - 1 per launch; ctclip_reduce_partials sums the rows in order).
 constexpr int PEG_CWW = 4;
 __global__ __launch_bounds__(256) void peg_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                             float* __restrict__ dw27, float* __restrict__ dbias, Grid5 g) {
+                                                             float* __restrict__ partials, Grid5 g, long group0, int ngroups) {
   const int wchunks = (g.W + PEG_CWW - 1) / PEG_CWW;
-  const long total = g.B * g.H * wchunks * g.d4;
+  const long total = (long)ngroups * g.d4;
   const long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   if (idx >= total) return;
   const int c = (int)(idx % g.d4);
-  long r = idx / g.d4;
+  const long part = idx / g.d4;
+  long r = group0 + part;
   const int wc = (int)(r % wchunks); r /= wchunks;
   const int h_ = (int)(r % g.H);
   const long b = r / g.H;
@@ -168,11 +170,9 @@ __global__ __launch_bounds__(256) void peg_bwd_weight_kernel(const float* __rest
 #pragma unroll
     for (int i = 0; i < PEG_CWW; ++i) { d[0][i] = d[1][i]; d[1][i] = d[2][i]; }
   }
+  float4* prow = (float4*)(partials + part * 28 * g.d4 * 4);
 #pragma unroll
-  for (int i = 0; i < 28; ++i) {
-    float* dst = (i < 27) ? dw27 + ((long)i * g.d4 + c) * 4 : dbias + c * 4;
-    atomicAdd(dst + 0, acc[i].x); atomicAdd(dst + 1, acc[i].y); atomicAdd(dst + 2, acc[i].z); atomicAdd(dst + 3, acc[i].w);
-  }
+  for (int i = 0; i < 28; ++i) prow[(long)i * g.d4 + c] = acc[i];
 }
 
 
@@ -333,7 +333,7 @@ constexpr int WG_C2 = 2 * PL_CG;    // float2 channel pairs per 16-channel slice
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __global__ __launch_bounds__(WG_MAXT) void peg_wgrad_plane_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                 float* __restrict__ dw27, float* __restrict__ dbias, Grid5 g,
+                                                                 float* __restrict__ partials, Grid5 g,
                                                                  int strips, int bchunk) {
   // one thread = 2 channels x PL_P consecutive w positions (float2 keeps the 28 accumulators at 56 registers)
   extern __shared__ __attribute__((aligned(16))) f32x2 wg_smem[];
@@ -449,8 +449,9 @@ __global__ __launch_bounds__(WG_MAXT) void peg_wgrad_plane_kernel(const float* _
     const int rc = idx / 28, i = idx % 28;
     f32x2 sum = zero;
     for (int wv = 0; wv < nwaves; ++wv) sum += red[(wv * WG_C2 + rc) * 28 + i];
-    float* dst = (i < 27) ? dw27 + ((long)i * d2 + slice * WG_C2 + rc) * 2 : dbias + (slice * WG_C2 + rc) * 2;
-    atomicAdd(dst + 0, sum[0]); atomicAdd(dst + 1, sum[1]);
+    // row (batch chunk) of `partials`: [28][d]; the chunks are added up in chunk order by ctclip_reduce_partials
+    float* dst = partials + ((long)(blk / nslices) * 28 + i) * (d2 * 2) + (slice * WG_C2 + rc) * 2;
+    dst[0] = sum[0]; dst[1] = sum[1];
   }
 }
 
@@ -527,17 +528,26 @@ int ctclip_peg_bwd_data(const float* dy, const float* w27, float* dx, void* dx_b
 }
 
 int ctclip_peg_bwd_weight(const float* dy, const float* x, float* dw27, float* dbias, long B, int T, int H, int W, int d,
-                          void* stream) {
+                          float* partials, void* stream) {
   const long npos = B * T * H * W;
   if (npos <= 0) return 0;
-  if ((d & 3) || d / 4 > 256) return (int)hipErrorInvalidValue;
+  if ((d & 3) || d / 4 > 256 || !partials) return (int)hipErrorInvalidValue;
   Grid5 g{B, T, H, W, d / 4};
+  hipStream_t st = (hipStream_t)stream;
+  const long rowf = 28L * d;                                 // floats per partial row: 27 taps + the bias sum
+  auto finish = [&](int nparts) -> int {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    int r = ctclip_reduce_partials(partials, nparts, rowf, 27 * d, dw27, st);
+    if (r == 0) r = ctclip_reduce_partials(partials + 27L * d, nparts, rowf, d, dbias, st);
+    return r;
+  };
   {
     int strips = 0;
     size_t plds = 0;
     const int threads = wgrad_plane_threads(H, W, d, &strips, &plds);
     if (threads > 0) {
-      // ~2 rounds of one-per-CU workgroups; more batch items per workgroup = fewer atomics
+      // ~2 rounds of one-per-CU workgroups; more batch items per workgroup = fewer partial rows
       static const int ncu = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
@@ -545,19 +555,28 @@ int ctclip_peg_bwd_weight(const float* dy, const float* x, float* dw27, float* d
       }();
       const int nslices = g.d4 / PL_CG;
       long nchunks = (2L * ncu) / nslices;
+      if (nchunks > kPartialsFloats / rowf) nchunks = kPartialsFloats / rowf;
       if (nchunks < 1) nchunks = 1;
       if (nchunks > B) nchunks = B;
       const int bchunk = (int)((B + nchunks - 1) / nchunks);
       nchunks = (B + bchunk - 1) / bchunk;
       if (plds > 65536) hipFuncSetAttribute((const void*)peg_wgrad_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
-      hipLaunchKernelGGL(peg_wgrad_plane_kernel, dim3((unsigned)(nchunks * nslices)), dim3(threads), plds, (hipStream_t)stream,
-                         dy, x, dw27, dbias, g, strips, bchunk);
-      CTCLIP_CHECK_LAUNCH();
+      hipLaunchKernelGGL(peg_wgrad_plane_kernel, dim3((unsigned)(nchunks * nslices)), dim3(threads), plds, st,
+                         dy, x, partials, g, strips, bchunk);
+      return finish((int)nchunks);
     }
   }
-  hipLaunchKernelGGL(peg_bwd_weight_kernel, dim3(grid_for(B * H * ((W + PEG_CWW - 1) / PEG_CWW) * g.d4)), dim3(256), 0,
-                     (hipStream_t)stream, dy, x, dw27, dbias, g);
-  CTCLIP_CHECK_LAUNCH();
+  // sweep kernel: one partial row per (b, h, w chunk) group, as many groups per launch as the scratch holds
+  const long ngroups = B * H * ((W + PEG_CWW - 1) / PEG_CWW);
+  long cap = kPartialsFloats / rowf;
+  if (cap < 1) return (int)hipErrorInvalidValue;
+  for (long g0 = 0; g0 < ngroups; g0 += cap) {
+    const int n = (int)((ngroups - g0 < cap) ? ngroups - g0 : cap);
+    hipLaunchKernelGGL(peg_bwd_weight_kernel, dim3(grid_for((long)n * g.d4)), dim3(256), 0, st, dy, x, partials, g, g0, n);
+    const int r = finish(n);
+    if (r) return r;
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -117,13 +117,21 @@ __global__ __launch_bounds__(256) void scale_by_dev_kernel(const float* __restri
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) y[e] = x[e] * k;
 }
 
-// out += sum(a * b)   (d temperature = sum(dsim * sim), CTCLIP tail backward)
+// one value per workgroup, summed in a fixed order: lanes by butterfly, the four waves left to right
+__device__ __forceinline__ void block_partial(float s, float* __restrict__ partials) {
+  __shared__ float wsum[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// partials[block] = sum(a * b) over the block's grid-stride share (d temperature = sum(dsim * sim), CTCLIP tail backward)
 __global__ __launch_bounds__(256) void dot_accum_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                        float* __restrict__ out, long n) {
+                                                        float* __restrict__ partials, long n) {
   float s = 0.f;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) s += a[e] * b[e];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  block_partial(s, partials);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void dot_accum_kernel(const float* __restrict_
 // (CTClipTrainer.py:199-202, optimizer.py:42-54).  The clip coefficient is computed on device from the
 // squared norm so the host never synchronises.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, long n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n4, long n, float* __restrict__ partials) {
   float s = 0.f;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
     const float4 v = ((const float4*)g)[e];
@@ -139,8 +147,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   }
   if (blockIdx.x == 0)
     for (long e = n4 * 4 + threadIdx.x; e < n; e += 256) s += g[e] * g[e];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+  block_partial(s, partials);
 }
 
 struct AdamArgs {
@@ -169,11 +176,11 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   }
 }
 
-// out[c] += sum_r x[r][c]: a workgroup covers 64 columns x rows_per_block rows, 4 row-lanes per column, LDS reduce,
-// one atomic per column per workgroup.
+// partials[chunk][c] = sum of x[r][c] over the chunk's rows: a workgroup covers 64 columns x rows_per_block rows, 4 row-lanes
+// per column combined through LDS in a fixed order; ctclip_reduce_partials adds the chunks up in chunk order.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long rows, int cols, long ld,
-                                                     float* __restrict__ out, int rows_per_block) {
+                                                     float* __restrict__ partials, int rows_per_block) {
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -187,7 +194,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
     }
   red[rl][cl] = s;
   __syncthreads();
-  if (rl == 0 && c < cols) atomicAdd(out + c, (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]));
+  if (rl == 0 && c < cols) partials[(long)blockIdx.y * cols + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second stage of every small reduction of the backward pass (column sums, LayerNorm / tubelet-norm d(gamma) d(beta),
+// head-norm d(scale), PEG d(taps), squared gradient norm): out[c] += sum over parts of partials[part * ld + c], parts
+// taken in index order by LANES interleaved row lanes whose totals are combined in a fixed tree -- the result does not
+// depend on which workgroup finished first, so two runs of the same step give the same bits (the reference asks for
+// torch.use_deterministic_algorithms(True) in its attribution code, src/utils/visualizations.py:29-39).
+// ------------------------------------------------------------------------------------------------
+template <int CPB>                                        // columns per workgroup: 16 (x 16 row lanes) or 1 (x 256)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, long ld,
+                                                              int width, float* __restrict__ out) {
+  constexpr int LANES = 256 / CPB;
+  __shared__ float red[LANES][CPB + 1];
+  const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB;
+  const int c = blockIdx.x * CPB + cl;
+  float s = 0.f;
+  if (c < width)
+    for (int b = rl; b < nparts; b += LANES) s += partials[(long)b * ld + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  for (int half = LANES / 2; half > 0; half >>= 1) {      // fixed pairing: lane r += lane r + half
+    if (rl < half) red[rl][cl] += red[rl + half][cl];
+    __syncthreads();
+  }
+  if (rl == 0 && c < width) out[c] += red[0][cl];
 }
 
 __global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ act,
@@ -204,6 +237,15 @@ inline unsigned grid_for(long work, long cap = 2048) {
 }
 
 }  // namespace
+
+int ctclip_reduce_partials(const float* partials, int nparts, long ld, int width, float* out, hipStream_t st) {
+  if (nparts <= 0 || width <= 0) return 0;
+  if (width >= 16)
+    hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3((width + 15) / 16), dim3(256), 0, st, partials, nparts, ld, width, out);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3(width), dim3(256), 0, st, partials, nparts, ld, width, out);
+  return (int)hipGetLastError();
+}
 
 extern "C" {
 
@@ -236,15 +278,24 @@ int ctclip_scale_by_dev(const float* x, const float* s, float* y, long n, void* 
   CTCLIP_CHECK_LAUNCH();
 }
 
-int ctclip_colsum_accum(const void* x, int x_is_bf16, long rows, int cols, long ld, float* out, void* stream) {
+int ctclip_colsum_accum(const void* x, int x_is_bf16, long rows, int cols, long ld, float* out, float* partials, void* stream) {
   if (rows <= 0 || cols <= 0) return 0;
-  const int rpb = 128;
-  dim3 grid((cols + 63) / 64, (unsigned)((rows + rpb - 1) / rpb));
+  if (!partials || cols > 8192) return (int)hipErrorInvalidValue;
+  // at most 256 row chunks (and CTCLIP_PARTIALS_FLOATS / cols), at least 128 rows each
+  long maxchunks = kPartialsFloats / cols;
+  if (maxchunks > 256) maxchunks = 256;
+  long rpb = (rows + maxchunks - 1) / maxchunks;
+  if (rpb < 128) rpb = 128;
+  rpb = (rpb + 3) / 4 * 4;
+  const int nchunks = (int)((rows + rpb - 1) / rpb);
+  dim3 grid((cols + 63) / 64, (unsigned)nchunks);
   if (x_is_bf16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, cols, ld, out, rpb);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, cols, ld, partials, (int)rpb);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, cols, ld, out, rpb);
-  CTCLIP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, cols, ld, partials, (int)rpb);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return ctclip_reduce_partials(partials, nchunks, cols, cols, out, (hipStream_t)stream);
 }
 
 int ctclip_leaky_bwd(const float* dy, const float* act, float* y, long n, float slope, void* stream) {
@@ -253,17 +304,24 @@ int ctclip_leaky_bwd(const float* dy, const float* act, float* y, long n, float 
   CTCLIP_CHECK_LAUNCH();
 }
 
-int ctclip_dot_accum(const float* a, const float* b, float* out, long n, void* stream) {
+int ctclip_dot_accum(const float* a, const float* b, float* out, long n, float* partials, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(dot_accum_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
-  CTCLIP_CHECK_LAUNCH();
+  if (!partials) return (int)hipErrorInvalidValue;
+  const unsigned nb = grid_for(n, 256);
+  hipLaunchKernelGGL(dot_accum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, partials, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return ctclip_reduce_partials(partials, (int)nb, 1, 1, out, (hipStream_t)stream);
 }
 
-int ctclip_sumsq_accum(const float* g, long n, float* out, void* stream) {
+int ctclip_sumsq_accum(const float* g, long n, float* out, float* partials, void* stream) {
   if (n <= 0) return 0;
-  if (((uintptr_t)g) & 15) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, g, n / 4, n, out);
-  CTCLIP_CHECK_LAUNCH();
+  if ((((uintptr_t)g) & 15) || !partials) return (int)hipErrorInvalidValue;
+  const unsigned nb = grid_for(n / 4 + 1);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, n / 4, n, partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return ctclip_reduce_partials(partials, (int)nb, 1, 1, out, (hipStream_t)stream);
 }
 
 int ctclip_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1,

@@ -40,9 +40,24 @@ def parse_header(path=HEADER):
     return protos
 
 
+PARTIALS_FLOATS = 1 << 21          # CTCLIP_PARTIALS_FLOATS of include/ctclip_hip.h
+_partials = {}
+
+
+def partials_scratch():
+    """The scratch behind the `partials` argument of the two-stage reductions: one buffer per (device, stream) -- kernels
+    of one stream run in order, so consecutive calls may share it."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    t = _partials.get(key)
+    if t is None:
+        t = _partials[key] = torch.empty(PARTIALS_FLOATS, dtype=torch.float32, device="cuda")
+    return t
+
+
 class _Hip:
     """Attribute access gives a checked wrapper: tensors -> device pointers, None -> NULL, the trailing
-    `stream` argument defaults to torch's current stream, a non-zero return raises RuntimeError."""
+    `stream` argument defaults to torch's current stream (and a `partials` argument just before it to this stream's
+    scratch buffer), a non-zero return raises RuntimeError."""
 
     def __init__(self):
         self._dll = None
@@ -106,8 +121,11 @@ class _Hip:
         cfn.argtypes = [t for t, _, _ in proto]
         nargs = len(proto)
         has_stream = proto[-1][1] == "stream"
+        has_partials = has_stream and nargs >= 2 and proto[-2][1] == "partials"
 
         def call(*args):
+            if has_partials and len(args) == nargs - 2:
+                args = (*args, partials_scratch())
             if has_stream and len(args) == nargs - 1:
                 args = (*args, torch.cuda.current_stream().cuda_stream)
             if len(args) != nargs:

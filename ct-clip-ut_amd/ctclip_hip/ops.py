@@ -637,6 +637,12 @@ class LinearF32Fn(Function):
 # patch embedding: gather + LN(F) + Linear(F, dim) + bias + LN(dim)          ctvit.py:44-52
 # ---------------------------------------------------------------------------------------------------
 class PatchEmbedFn(Function):
+    """The affine part of LayerNorm(F) is folded into the projection (include/ctclip_hip.h: ctclip_patch_affine_fold):
+    z = xhat (W gamma)^T + (b + W beta).  The GEMM operand `A` is then the plain normalised tubelet row, and the backward
+    needs ONE product over the tokens, G = dz^T xhat: d(W), d(gamma), d(beta) all follow from G and colsum(dz)
+    (ctclip_patch_affine_bwd) -- the [tokens, F] data gradient dz W and the pass over it are only formed when the volume
+    itself is differentiated (integrated gradients)."""
+
     @staticmethod
     def forward(ctx, volume, ln1w, ln1b, w, b, ln2w, ln2b, sh, geom):
         patch, tpatch = geom
@@ -653,9 +659,8 @@ class PatchEmbedFn(Function):
         A = torch.empty(M, ldA, dtype=BF16, device=vol.device)
         mean1 = torch.empty(M, dtype=F32, device=vol.device)
         rstd1 = torch.empty(M, dtype=F32, device=vol.device)
-        hip.patch_ln_fwd(vol, int(is16), ln1w.detach(), ln1b.detach(), A, mean1, rstd1, B, C, Dz, Hy, Wx, tpatch, patch,
-                         ldA, 1e-5)
-        z = gemm(A, sh["w"], M, dim, ldA, out_dtype=F32, bias=b.detach())
+        hip.patch_ln_fwd(vol, int(is16), sh["ones"], sh["zeros"], A, mean1, rstd1, B, C, Dz, Hy, Wx, tpatch, patch, ldA, 1e-5)
+        z = gemm(A, sh["w"], M, dim, ldA, out_dtype=F32, bias=sh["b"])
         _, y, mean2, rstd2 = layernorm(z, ln2w.detach(), ln2b.detach(), 1e-5, want16=False, want32=True)
         ctx.save_for_backward(vol, A, mean1, rstd1, z, mean2, rstd2, ln2w)
         ctx.sh, ctx.geom, ctx.dims = sh, geom, (B, C, Dz, Hy, Wx, F_, ldA, dim, M)
@@ -677,18 +682,19 @@ class PatchEmbedFn(Function):
         d2w, k1 = grad_slot(p_l2w)
         d2b, k2 = grad_slot(p_l2b)
         hip.layernorm_bwd(dy2, z, ln2w, mean2, rstd2, None, dz, dzb, d2w, d2b, M, dim)
+        db_now = colsum(dz)                                          # this call's sum: the folded terms below need it alone
         db, k3 = grad_slot(p_b)
-        colsum(dz, out=db)
+        db += db_now
+        G = wgrad(dzb, A, dim, F_, M)                                # dz^T xhat, [dim, F] f32
         dw, k4 = grad_slot(p_w)
-        wgrad(dzb, A, dim, F_, M, out=dw)
-        dA = dgrad(dzb, sh["w"], M, dim, ldA, out_dtype=BF16, wT16=sh.get("wT"))
         d1w, k5 = grad_slot(p_l1w)
         d1b, k6 = grad_slot(p_l1b)
-        hip.patch_ln_bwd(vol, int(vol.dtype == BF16), dA, ldA, mean1, rstd1, d1w, d1b, B, C, Dz, Hy, Wx, tpatch, patch)
+        hip.patch_affine_bwd(G, db_now, _c(p_w.detach()), p_l1w.detach(), p_l1b.detach(), dw, d1w, d1b, dim, F_)
         dvol = None
         if ctx.needs_input_grad[0]:                    # input attribution only (integrated gradients)
+            dA = dgrad(dzb, sh["w"], M, dim, ldA, out_dtype=BF16, wT16=sh.get("wT"))      # d(xhat) = dz (W gamma)
             dvol = torch.empty(vol.shape, dtype=F32, device=dev)
-            hip.patch_ln_bwd_dx(vol, int(vol.dtype == BF16), dA, ldA, p_l1w.detach(), mean1, rstd1, dvol, B, C, Dz, Hy, Wx,
+            hip.patch_ln_bwd_dx(vol, int(vol.dtype == BF16), dA, ldA, sh["ones"], mean1, rstd1, dvol, B, C, Dz, Hy, Wx,
                                 tpatch, patch)
             dvol = dvol.to(vol.dtype)
         return dvol, _ret(d1w, k5), _ret(d1b, k6), _ret(dw, k4), _ret(db, k3), _ret(d2w, k1), _ret(d2b, k2), None, None

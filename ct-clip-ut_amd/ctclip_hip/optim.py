@@ -329,6 +329,7 @@ class GradSync:
             return
         if not self.opt._built:
             self.opt._build()
+            arenas = self.opt._arenas                        # _build() replaces the list
         for ai, a in enumerate(arenas):
             if a is None:
                 continue

@@ -72,10 +72,18 @@ class CTViT(nn.Module):
             raise RuntimeError("CTViT: MI355X HIP path only (no CPU fallback); move the volume to cuda")
         _, ln1, lin, ln2 = self.to_patch_emb
         def build():
-            w = torch.nn.functional.pad(lin.weight, (0, ops.pad8(lin.weight.shape[1]) - lin.weight.shape[1])).to(BF16).contiguous()
-            return {"w": w, "wT": w.t().contiguous()}
+            # LayerNorm(F)'s gamma / beta folded into the projection (ctclip_patch_affine_fold): the GEMM operand is the plain
+            # normalised tubelet row, weight W * gamma (bf16, K padded to 8), bias b + W beta
+            N, F_ = lin.weight.shape
+            ldw = ops.pad8(F_)
+            wg = torch.empty(N, ldw, dtype=BF16, device=lin.weight.device)
+            bfold = torch.empty(N, dtype=F32, device=lin.weight.device)
+            ops.hip.patch_affine_fold(lin.weight.detach().contiguous(), lin.bias.detach(), ln1.weight.detach(), ln1.bias.detach(),
+                                      wg, bfold, N, F_, ldw)
+            return {"w": wg, "wT": wg.t().contiguous(), "b": bfold,
+                    "ones": torch.ones(F_, dtype=F32, device=wg.device), "zeros": torch.zeros(F_, dtype=F32, device=wg.device)}
 
-        sh = self._shadow.get("patch", (lin.weight,), build)
+        sh = self._shadow.get("patch", (lin.weight, lin.bias, ln1.weight, ln1.bias), build)
         if image.dtype not in (F32, BF16):
             image = image.to(F32)
         return ops.PatchEmbedFn.apply(image, ln1.weight, ln1.bias, lin.weight, lin.bias, ln2.weight, ln2.bias, sh,

@@ -18,7 +18,18 @@
  *   - all pointers are DEVICE pointers owned by the caller; "bf16" buffers are raw uint16 storage.
  *   - matrices are row-major; `ld*` are row strides in ELEMENTS.  bf16 matrices need 16-byte aligned
  *     base pointers and strides that are multiples of 8.
- *   - gradient outputs named d<param> are ACCUMULATED with f32 atomics: the caller zeroes them.
+ *   - gradient outputs named d<param> are ACCUMULATED into what the caller passes (the caller zeroes them).
+ *   - reproducibility (the reference's attribution code asks for torch.use_deterministic_algorithms(True),
+ *     src/utils/visualizations.py:29-39).  Every entry point with a `partials` argument reduces in two stages -- a row of
+ *     partial sums per workgroup, stored with plain stores into `partials` (caller-provided scratch of at least
+ *     CTCLIP_PARTIALS_FLOATS floats, private to the stream while the call runs), then added up in row order -- so its outputs
+ *     are bit-identical from run to run: LayerNorm / head-norm / PEG parameter gradients, bias-gradient column sums, the
+ *     squared gradient norm, d(temperature).  All forward kernels and all DATA gradients (dx, dq, dk, dv ...) are
+ *     reproducible too.
+ *     ORDER-DEPENDENT (f32 atomics, last-bit differences between runs): split-K products of ctclip_gemm_bf16 with
+ *     accumulate=1 / split_k>1 (the weight gradients, the 294 912 -> 512 visual projection) and what is derived from one
+ *     (ctclip_patch_affine_bwd is itself reproducible, but its input G is a split-K product), d(bias) of ctclip_attn_bwd
+ *     (table and dense), ctclip_bert_embed_bwd (scatter-add by token id), embed_sum of ctclip_vq_ema_accum.
  */
 #ifndef CTCLIP_HIP_H
 #define CTCLIP_HIP_H
@@ -26,6 +37,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* floats of scratch behind every `partials` argument (8 MiB) */
+#define CTCLIP_PARTIALS_FLOATS (1L << 21)
 
 /* ---- GEMM (MFMA) -------------------------------------------------------------------------------
  * C[M,N] = alpha * opA(A) opB(B) (+bias[N]) (+resid[M,N]) ; act: 0 none, 1 erf-GELU (anything else:
@@ -54,10 +68,10 @@ int ctclip_vq_topk(const void* A, const void* B, float* part_val, int* part_idx,
 /* ---- LayerNorm: attention.py:27-34 (beta==NULL), attention.py:46, ctvit.py:51, BertLayerNorm ---- */
 int ctclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                          float* mean, float* rstd, int rows, int dim, float eps, void* stream);
-/* dx = dres + LN'(dy); optional bf16 copy of dx; dgamma/dbeta accumulated. */
+/* dx = dres + LN'(dy); optional bf16 copy of dx; dgamma/dbeta accumulated (dbeta may be NULL). */
 int ctclip_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                          const float* dres, float* dx, void* dx_bf16, float* dgamma, float* dbeta, int rows, int dim,
-                         void* stream);
+                         float* partials, void* stream);
 /* same with the LN-path gradient in bf16 (the output of a bf16 data-gradient GEMM) and an optional second, bf16,
  * residual-path term: dx = dres + dres2 + LN'(dy).  (the K/V projection of attention.py:138 reads the un-normalised x, so
  * its data gradient by-passes LN'.) */
@@ -68,17 +82,17 @@ int ctclip_layernorm_swap_fwd(const float* x, const float* gamma, const float* b
                               int rows, int dim, float eps, int A, int C, void* stream);
 int ctclip_layernorm_swap_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                               float* dx, void* dx_bf16, float* dgamma, float* dbeta, int rows, int dim, int A, int C,
-                              void* stream);
+                              float* partials, void* stream);
 int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* dres, const void* dres2_bf16, float* dx, void* dx_bf16, float* dgamma,
-                              float* dbeta, int rows, int dim, void* stream);
+                              float* dbeta, int rows, int dim, float* partials, void* stream);
 
 /* ---- per-head cosine normalisation: y = x/|x| * scale[d] * mult   (attention.py:151-153,155) ---- */
 int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_norm, long rows, int heads, int dhead,
                         long ldx, long ldy, float mult, void* stream);
 int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
                         float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
-                        void* stream);
+                        float* partials, void* stream);
 
 /* ---- fused attention (attention.py:155-180; BertSelfAttention) ----------------------------------
  * q,k,v,o: [nseq*n, ld] bf16, head h in columns h*dhead.. ; dhead in {32,64}.
@@ -147,16 +161,23 @@ int ctclip_peg_fwd(const float* x, const float* w27, const float* bias, float* y
 int ctclip_peg_bwd_data(const float* dy, const float* w27, float* dx, void* dx_bf16, long B, int T, int H, int W, int d,
                         int residual, void* stream);
 int ctclip_peg_bwd_weight(const float* dy, const float* x, float* dw27, float* dbias, long B, int T, int H, int W, int d,
-                          void* stream);
+                          float* partials, void* stream);
 
 /* ---- tubelet gather + LayerNorm(c*pt*p*p) -> bf16 GEMM operand [tokens, ldA] (ctvit.py:44-49) ----
  * volume: [B,C,Dz,Hy,Wx] f32 or bf16; pad columns F..ldA-1 are written as zero. */
 int ctclip_patch_ln_fwd(const void* volume, int volume_is_bf16, const float* gamma, const float* beta, void* A_bf16,
                         float* mean, float* rstd, int B, int C, int Dz, int Hy, int Wx, int pt, int p, long ldA,
                         float eps, void* stream);
-int ctclip_patch_ln_bwd(const void* volume, int volume_is_bf16, const void* dA_bf16, long ldd, const float* mean,
-                        const float* rstd, float* dgamma, float* dbeta, int B, int C, int Dz, int Hy, int Wx, int pt,
-                        int p, void* stream);
+/* The affine part of that LayerNorm folded into the tubelet projection (ctvit.py:49-50):
+ *   z = (xhat gamma + beta) W^T + b = xhat (W gamma)^T + (b + W beta), so ctclip_patch_ln_fwd is called with gamma = 1, beta = 0
+ *   and the GEMM with Wg_bf16[N][ldw] = bf16(W[n][f] gamma[f]) (pad columns zero) and bias_folded[n] = b[n] + sum_f W[n][f] beta[f].
+ * Backward, from G[N,F] = dz^T xhat (f32, the one weight-gradient product) and db[N] = colsum(dz):
+ *   dW[n][f] += G gamma[f] + db[n] beta[f];  dgamma[f] += sum_n W[n][f] G[n][f];  dbeta[f] += sum_n W[n][f] db[n]
+ * -- exact, and no [tokens, F] gradient is ever formed.  W is [N][F] f32 contiguous (nn.Linear weight). */
+int ctclip_patch_affine_fold(const float* W, const float* bias, const float* gamma, const float* beta, void* Wg_bf16,
+                             float* bias_folded, int N, int F, long ldw, void* stream);
+int ctclip_patch_affine_bwd(const float* G, const float* db, const float* W, const float* gamma, const float* beta, float* dW,
+                            float* dgamma, float* dbeta, int N, int F, void* stream);
 /* d(volume) [B,C,Dz,Hy,Wx] f32 of the gather + LayerNorm above (input attribution: integrated gradients,
  * src/utils/visualizations.py:851-910; training never needs it). */
 int ctclip_patch_ln_bwd_dx(const void* volume, int volume_is_bf16, const void* dA_bf16, long ldd, const float* gamma,
@@ -190,14 +211,14 @@ int ctclip_infonce(const float* sim, float* loss, float* dsim, int G, float* wor
 int ctclip_bias_expand(const float* table, const uint16_t* relidx, float* bias, int heads, int n, void* stream);
 int ctclip_scale_by_dev(const float* x, const float* s, float* y, long n, void* stream);
 /* out[c] += sum_r x[r][c] (bias gradients); x is f32 or bf16 with row stride ld */
-int ctclip_colsum_accum(const void* x, int x_is_bf16, long rows, int cols, long ld, float* out, void* stream);
+int ctclip_colsum_accum(const void* x, int x_is_bf16, long rows, int cols, long ld, float* out, float* partials, void* stream);
 /* y = dy * (act > 0 ? 1 : slope): backward of leaky_relu given its OUTPUT (attention.py:18-19) */
 int ctclip_leaky_bwd(const float* dy, const float* act, float* y, long n, float slope, void* stream);
-int ctclip_dot_accum(const float* a, const float* b, float* out, long n, void* stream);
+int ctclip_dot_accum(const float* a, const float* b, float* out, long n, float* partials, void* stream);
 
 /* ---- optimiser (CTClipTrainer.py:199-202, optimizer.py:42-54): out += sum(g^2); clip + Adam/AdamW over a flat
  * arena, clip coefficient min(1, max_norm/(sqrt(*gnorm_sq)+1e-6)) computed on device; optional bf16 shadow ---- */
-int ctclip_sumsq_accum(const float* g, long n, float* out, void* stream);
+int ctclip_sumsq_accum(const float* g, long n, float* out, float* partials, void* stream);
 int ctclip_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int decoupled, float bias_corr1, float bias_corr2,
                      const float* gnorm_sq, float max_norm, void* stream);

@@ -112,7 +112,8 @@ def randomize(module, gen, scale=0.5):
 # ---- A. building blocks (reference src/utils/attention.py) --------------------------------
 def blocks():
     g = torch.Generator().manual_seed(11)
-    out = {}
+    torch.manual_seed(11)          # module constructors draw their initial weights from the GLOBAL generator: seed it too,
+    out = {}                       # so that this fixture regenerates bit for bit (every other generator already does)
     dim, heads, dh = 56, 4, 8
 
     ln = RA.LayerNorm(dim)
@@ -251,11 +252,17 @@ def ctclip():
         for k, v in txt.items():
             out[f"step{s}.{k}"] = v
 
+    # the nearest-code decisions of every forward below (the VQ output's second element): an arg-max, so a reduced-precision
+    # implementation may flip genuine near-ties; the HIP parity tests pin the decisions to these to separate the continuous
+    # arithmetic from the flips (and count the flips on their own)
+    codes = []
+    hook = vit.vq.register_forward_hook(lambda m, i, o: codes.append(o[1].detach().clone()))
+
     # forward-only record in eval mode (frozen codebook)
     clip.eval()
     sim, il, tl, temp, toks = clip(batches[0][0], batches[0][1])
     out.update({"eval.sim": sim, "eval.image_latents": il, "eval.text_latents": tl, "eval.temp": temp,
-                "eval.image_tokens": toks})
+                "eval.image_tokens": toks, "eval.indices": codes.pop()})
 
     # two training steps: CTClipTrainer.train_step order without Accelerate (fp32, 1 process)
     clip.train()
@@ -276,6 +283,8 @@ def ctclip():
         out[f"step{s}.loss"] = loss.detach()
         out[f"step{s}.grad_norm"] = norm
         out[f"step{s}.sim"] = sim.detach()
+        out[f"step{s}.indices"] = codes.pop()
+    hook.remove()
     for k in ("to_text_latent.weight", "temperature",
               "visual_transformer.enc_spatial_transformer.layers.0.1.to_q.weight",
               "visual_transformer.to_patch_emb.2.bias",

@@ -627,11 +627,34 @@ def test_patch_ln_forward_and_volume_gradient(hip, in16, geom):
     dvol = torch.empty(B, C, Dz, Hy, Wx, device=DEV)
     hip.patch_ln_bwd_dx(vol, int(in16), dA, ldA, gm, mean, rstd, dvol, B, C, Dz, Hy, Wx, pt, p)
     check("patch ln d(volume)", dvol, vr.grad, 2e-5)
-    dg, db = torch.zeros(F_, device=DEV), torch.zeros(F_, device=DEV)
-    hip.patch_ln_bwd(vol, int(in16), dA, ldA, mean, rstd, dg, db, B, C, Dz, Hy, Wx, pt, p)
-    xhat = (rows.detach() - mean[:, None]) * rstd[:, None]
-    check("patch ln dgamma", dg, (dA.float() * xhat).sum(0), 2e-5)
-    check("patch ln dbeta", db, dA.float().sum(0), 2e-5)
+
+
+@pytest.mark.parametrize("N,F_,M", [(24, 40, 96), (64, 4000, 200), (16, 8, 50)])
+def test_patch_affine_fold_and_backward(hip, N, F_, M):
+    """ctclip_patch_affine_fold / _bwd: LayerNorm(F)'s gamma / beta folded into the tubelet projection (reference
+    src/utils/ctvit.py:49-50).  Forward identity and the three parameter gradients against torch autograd of the UNFOLDED
+    expression z = (xhat * gamma + beta) W^T + b on the same xhat, dz (all f32: the algebra is what is checked)."""
+    xhat = rnd(M, F_, seed=60)
+    W, b = rnd(N, F_, seed=61) * 0.1, rnd(N, seed=62)
+    gm, bt = (1 + 0.3 * rnd(F_, seed=63)), 0.2 * rnd(F_, seed=64)
+    Wr, br, gr, btr = (t.clone().requires_grad_(True) for t in (W, b, gm, bt))
+    z = (xhat * gr + btr) @ Wr.t() + br
+    dz = rnd(M, N, seed=65)
+    z.backward(dz)
+    ldw = (F_ + 7) // 8 * 8
+    Wg = torch.full((N, ldw), 7.0, device=DEV, dtype=torch.bfloat16)
+    bfold = torch.empty(N, device=DEV)
+    hip.patch_affine_fold(W, b, gm, bt, Wg, bfold, N, F_, ldw)
+    check("folded weight", Wg[:, :F_], W * gm, 4e-3)
+    assert float(Wg[:, F_:].float().abs().max()) == 0.0 if ldw > F_ else True
+    check("folded bias", bfold, b + W @ bt, 1e-5)
+    check("folded forward", xhat @ (W * gm).t() + (b + W @ bt), z.detach(), 1e-5)
+    G, db = dz.t() @ xhat, dz.sum(0)
+    dW, dg, dbt = torch.ones(N, F_, device=DEV), torch.ones(F_, device=DEV), torch.ones(F_, device=DEV)   # accumulate on top
+    hip.patch_affine_bwd(G.contiguous(), db, W, gm, bt, dW, dg, dbt, N, F_)
+    check("d(W)", dW - 1, Wr.grad, 1e-5)
+    check("d(gamma)", dg - 1, gr.grad, 1e-5)
+    check("d(beta)", dbt - 1, btr.grad, 1e-5)
 
 
 # ---------------------------------------------------------------------------------------------- PEG
@@ -718,3 +741,78 @@ def test_elementwise(hip):
     c16 = torch.empty(64, device=DEV, dtype=torch.bfloat16)
     hip.cast_f32_bf16(a, c16, 64)
     assert torch.equal(c16, a.to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------------------- reproducibility
+def test_two_stage_reductions_are_bitwise_reproducible(hip):
+    """include/ctclip_hip.h, "reproducibility": every entry point with a `partials` argument gives the same bits on every
+    run (the reference's attribution code asks for deterministic algorithms, src/utils/visualizations.py:29-39).  Each is
+    run several times on the same inputs -- with unrelated work in between to perturb workgroup scheduling -- and compared
+    with torch.equal; values are checked against f32 torch."""
+    rows, dim = 5000, 512
+    x, dy = rnd(rows, dim, seed=70), rnd(rows, dim, seed=71)
+    gm = 1 + 0.2 * rnd(dim, seed=72)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    y = torch.empty(rows, dim, device=DEV)
+    hip.layernorm_fwd(x, gm, None, None, y, mean, rstd, rows, dim, 1e-5)
+    noise = rnd(1 << 20, seed=73)
+
+    def run_all():
+        out = {}
+        dg, db, dx = torch.zeros(dim, device=DEV), torch.zeros(dim, device=DEV), torch.empty(rows, dim, device=DEV)
+        hip.layernorm_bwd(dy, x, gm, mean, rstd, None, dx, None, dg, db, rows, dim)
+        out["ln dgamma"], out["ln dbeta"], out["ln dx"] = dg, db, dx
+        noise.mul_(1.0)                                                   # something else on the stream
+        H, D = 8, 32
+        q, dq = bf(rnd(rows, H * D, seed=74)), bf(rnd(rows, H * D, seed=75))
+        sc = 1 + 0.1 * rnd(D, seed=76)
+        qn, inv = torch.empty_like(q), torch.empty(rows, H, device=DEV)
+        hip.headnorm_fwd(q, sc, qn, inv, rows, H, D, H * D, H * D, 8.0)
+        dxh, ds = torch.empty_like(q), torch.zeros(D, device=DEV)
+        hip.headnorm_bwd(dq, q, inv, sc, dxh, ds, rows, H, D, H * D, H * D, H * D, 8.0)
+        out["headnorm dscale"] = ds
+        cs = torch.zeros(dim, device=DEV)
+        hip.colsum_accum(dy, 0, rows, dim, dim, cs)
+        out["colsum f32"] = cs
+        cs16 = torch.zeros(dim, device=DEV)
+        hip.colsum_accum(bf(dy), 1, rows, dim, dim, cs16)
+        out["colsum bf16"] = cs16
+        ss, dt = torch.zeros((), device=DEV), torch.zeros((), device=DEV)
+        hip.sumsq_accum(x.reshape(-1), x.numel(), ss)
+        hip.dot_accum(x.reshape(-1), dy.reshape(-1), dt, x.numel())
+        out["sumsq"], out["dot"] = ss, dt
+        B, T, Hh, Ww, d = 3, 4, 24, 24, 32
+        px, pdy = rnd(B, T, Hh, Ww, d, seed=77), rnd(B, T, Hh, Ww, d, seed=78)
+        dw27, dbias = torch.zeros(27, d, device=DEV), torch.zeros(d, device=DEV)
+        hip.peg_bwd_weight(pdy, px, dw27, dbias, B, T, Hh, Ww, d)
+        out["peg dw"], out["peg dbias"] = dw27, dbias
+        return out
+
+    first = run_all()
+    xh = (x - mean[:, None]) * rstd[:, None]
+    check("ln dgamma value", first["ln dgamma"], (dy * xh).sum(0), 1e-5)
+    check("colsum value", first["colsum f32"], dy.sum(0), 1e-5)
+    check("sumsq value", first["sumsq"], (x.double() ** 2).sum().float(), 1e-5)
+    check("dot value", first["dot"], (x.double() * dy.double()).sum().float(), 1e-4)
+    for rep in range(3):
+        again = run_all()
+        for k, v in first.items():
+            assert torch.equal(v, again[k]), f"{k} differs between two runs of the same kernel on the same inputs"
+
+
+def test_gelu_tail_saturates(hip):
+    """The transcendental-free Phi(x) of the GELU epilogues (csrc/common.h) must reach 0 / 1 outside its fitted range: gelu(x)
+    for x in [-8, -3.7] is 0 up to 4e-4 (the true values are below that), not a leak proportional to |x|; and on the whole
+    real line the activation stays within 4e-4 of erf-GELU.  Checked through the elementwise kernels (bf16 in / out)."""
+    x = torch.cat([torch.linspace(-8.0, -3.7, 2048), torch.linspace(-3.7, 3.7, 4096), torch.linspace(3.7, 8.0, 2048)]).to(DEV)
+    h = bf(x)
+    m = torch.empty_like(h)
+    hip.gelu_fwd(h, m, h.numel())
+    ref = torch.nn.functional.gelu(h.float())
+    err = (m.float() - ref).abs()
+    tail = h.float() < -3.7
+    print(f"  gelu: max |err| {float(err.max()):.2e}; on x < -3.7: max |gelu| {float(m.float()[tail].abs().max()):.2e}")
+    assert float(m.float()[tail].abs().max()) <= 4e-4
+    assert float((err - 4e-3 * ref.abs()).max()) <= 4e-4                 # bf16 output rounding + the approximation
+    big = h.float() > 3.7
+    assert torch.equal(m[big], h[big])                                   # Phi = 1 exactly: gelu(x) = x

@@ -320,14 +320,31 @@ def batches(g):
     return out
 
 
+def code_agreement(vq, ref_idx, label, floor):
+    """Free-running nearest-code decisions against the reference's: an arg-max over bf16 encoder outputs flips genuine
+    near-ties (the reference under fp16 autocast does too), so the CONTINUOUS arithmetic is compared with the decisions
+    pinned to the reference's (VectorQuantize.forced_indices) and the flips are counted here."""
+    got = vq.last_indices.reshape(-1).cpu()
+    agree = float((got == ref_idx.reshape(-1)).float().mean())
+    print(f"  {label}: {agree:.4f} of {got.numel()} nearest-code decisions equal the reference's")
+    assert agree >= floor, (label, agree)
+    return agree
+
+
 def test_ctclip_eval_forward_golden():
     g = load_golden("ctclip")
     clip = build_clip(g).eval()
     vol, txt = batches(g)[0]
+    vq = clip.visual_transformer.vq
+    clip(txt, vol)                                                  # free-running: how many decisions flip
+    code_agreement(vq, g["eval.indices"], "eval forward", 0.9)
+    vq.forced_indices = g["eval.indices"].reshape(vol.shape[0], -1)
     sim, il, tl, temp, toks = clip(txt, vol)
+    vq.forced_indices = None
     check("text latents", tl, g["eval.text_latents"], 3e-2)
-    check("image latents", il, g["eval.image_latents"], 5e-2)
-    check("sim", sim, g["eval.sim"], 5e-2)
+    check("image tokens (pinned codes)", toks, g["eval.image_tokens"], 1e-5)
+    check("image latents", il, g["eval.image_latents"], 2e-2)
+    check("sim", sim, g["eval.sim"], 2e-2)
     check("exp(temp)", temp, g["eval.temp"], 1e-6)
 
 
@@ -338,8 +355,13 @@ def test_ctclip_training_steps_golden():
     clip = build_clip(g)
     trainer = CTClipTrainer(clip, batch_size=3, lr=1.25e-5, wd=0.0, max_grad_norm=0.5, results_folder=None)
     ref_grads = sub(g, "step0.grad.")
+    vq = clip.visual_transformer.vq
     for s, batch in enumerate(batches(g)):
+        # the reference's nearest-code decisions of this step (an arg-max: see code_agreement); the step itself -- forward,
+        # backward, clip, Adam, EMA codebook update -- runs on them
+        vq.forced_indices = g[f"step{s}.indices"].reshape(batch[0].shape[0], -1)
         loss = trainer.train_step(batch)
+        vq.forced_indices = None
         ref = float(g[f"step{s}.loss"])
         rel = abs(loss - ref) / abs(ref)
         print(f"  step {s}: loss {loss:.6f} ref {ref:.6f} rel {rel:.2e}; grad-norm {trainer.optim.grad_norm():.4f} "
@@ -368,13 +390,14 @@ def test_ctclip_training_steps_golden():
         worst = float((final[k].detach().cpu() - ref_w).abs().max())
         print(f"    largest element deviation {worst:.2e} (bound {6 * 1.25e-5:.2e})")
         assert worst <= 6 * 1.25e-5, k
-    # EMA codebook after two training forwards (decay 0.8): free-running codes, so a few rows may differ
+    # EMA codebook after two training forwards (decay 0.8) on the pinned decisions: every row follows the reference's
+    # (bf16 encoder outputs enter the running sums)
     emb, emb_ref = final["visual_transformer.vq._codebook.embed"].cpu(), g["final.visual_transformer.vq._codebook.embed"]
-    row_ok = ((emb - emb_ref).abs().amax(-1) <= 1e-3).float().mean()
-    print(f"  codebook rows equal to the reference's after two EMA updates: {float(row_ok):.3f}")
-    assert float(row_ok) >= 0.9
+    row_err = float((emb - emb_ref).abs().amax(-1).max())
+    print(f"  codebook after two EMA updates: worst row deviation {row_err:.2e}")
+    assert row_err <= 2e-2
     cs, cs_ref = final["visual_transformer.vq._codebook.cluster_size"].cpu(), g["final.visual_transformer.vq._codebook.cluster_size"]
-    assert float((cs - cs_ref).abs().sum()) <= 0.1 * float(cs_ref.abs().sum()) + 1e-6
+    assert float((cs - cs_ref).abs().max()) <= 1e-5
 
 
 # ------------------------------------------------------------------------------------------- BASELINE config 1

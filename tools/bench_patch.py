@@ -22,5 +22,7 @@ def timeit(fn, n=5):
 gb = (vol.numel() * 2 + A.numel() * 2) / 1e9
 t = timeit(lambda: hip.patch_ln_fwd(vol, 1, gm, bt, A, mean, rstd, B, 1, 240, 480, 480, 10, 20, F_, 1e-5))
 print(f"patch_ln_fwd {t:9.1f} us  {gb / t * 1e6 / 1e3:5.2f} TB/s")
-t = timeit(lambda: hip.patch_ln_bwd(vol, 1, dA, F_, mean, rstd, dg, db, B, 1, 240, 480, 480, 10, 20))
-print(f"patch_ln_bwd {t:9.1f} us  {gb / t * 1e6 / 1e3:5.2f} TB/s")
+G, W = torch.randn(512, F_, device="cuda"), torch.randn(512, F_, device="cuda")
+dW, dbv = torch.zeros(512, F_, device="cuda"), torch.randn(512, device="cuda")
+t = timeit(lambda: hip.patch_affine_bwd(G, dbv, W, gm, bt, dW, dg, db, 512, F_))
+print(f"patch_affine_bwd {t:9.1f} us (folded d(W) / d(gamma) / d(beta) of LayerNorm(4000): no pass over the tokens)")

@@ -1,5 +1,12 @@
-"""Run-to-run reproducibility of the gradients of one small CT-CLIP step (BASELINE config 1 shapes).  Atomics order alone
-moves gradients by ~1e-6 of their peak; a race between streams or inside a kernel shows up orders of magnitude above.
+"""Run-to-run reproducibility of the gradients of one small CT-CLIP step (BASELINE config 1 shapes), per gradient class.
+
+include/ctclip_hip.h ("reproducibility") states which outputs are bit-reproducible: everything reduced in two stages --
+i.e. the gradient of every 1-D parameter whose upstream is reproducible.  Order-dependent are the split-K weight
+gradients (2-D), the relative-position d(bias) (and so the position MLP behind it), the embedding scatter-adds and the tubelet
+LayerNorm(4000) (its d(gamma) / d(beta) are derived from a split-K product); those
+move by ~1e-6 of their peak.  A race between streams or inside a kernel shows up orders of magnitude above that.
+The forward is made reproducible here by taking the visual projection's split-K out of the picture (its [B, 512] output
+is a sum of f32 atomics): gradients are compared for a FIXED upstream gradient of the image tokens and of the text CLS.
 usage: flake_check.py [RUNS]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,17 +30,36 @@ gen = torch.Generator().manual_seed(1234)
 vol = (torch.randn(4, 1, 64, 64, 64, generator=gen) * 0.5).clamp(-1, 1).cuda()
 ids = torch.randint(0, 211, (4, 32), generator=gen)
 txt = {"input_ids": ids.cuda(), "token_type_ids": torch.zeros_like(ids).cuda(), "attention_mask": torch.ones_like(ids).cuda()}
+ORDER_DEPENDENT = ("spatial_rel_pos_bias.", "embeddings.word_embeddings", "embeddings.position_embeddings",
+                   "embeddings.token_type_embeddings",
+                   "to_patch_emb.1.")      # LayerNorm(4000): d(gamma) / d(beta) follow from G = dz^T xhat, a split-K product
 ref = None
+dev = torch.device("cuda")
+tok_g = cls_g = None
+worst_1d = worst_2d = worst_od = 0.0
 for run in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
     clip.zero_grad(set_to_none=True)
-    sim, *_ = clip(txt, vol)
-    loss = ops.InfoNCEFn.apply(sim)
-    loss.backward()
+    tokens = clip.visual_transformer(vol)
+    cls = clip.encode_text(txt)
+    if tok_g is None:
+        g = torch.Generator(device=dev).manual_seed(7)
+        tok_g = torch.randn(tokens.shape, generator=g, device=dev) * 1e-3
+        cls_g = torch.randn(cls.shape, generator=g, device=dev) * 1e-3
+    torch.autograd.backward([tokens, cls], [tok_g, cls_g])
     torch.cuda.synchronize()
     grads = {k: p.grad.detach().clone() for k, p in clip.named_parameters() if p.grad is not None}
     if ref is None:
         ref = grads
-        print(f"run 0: loss {float(loss):.6f}, {len(grads)} gradients")
+        print(f"run 0: {len(grads)} gradients ({sum(1 for g_ in grads.values() if g_.ndim <= 1)} of 1-D parameters)")
         continue
-    worst = max(((float((grads[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-20)), k) for k in ref), key=lambda t: t[0])
-    print(f"run {run}: loss {float(loss):.6f}  worst run-to-run gradient difference {worst[0]:.2e} at {worst[1]}", flush=True)
+    line = {}
+    for k in ref:
+        d = float((grads[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-20))
+        cls_ = "order-dependent (d(bias) / embedding scatter)" if any(t in k for t in ORDER_DEPENDENT) else (
+            "1-D parameters" if ref[k].ndim <= 1 else "split-K weight gradients")
+        if d >= line.get(cls_, (-1.0, ""))[0]:
+            line[cls_] = (d, k)
+    worst_1d = max(worst_1d, line.get("1-D parameters", (0.0, ""))[0])
+    print(f"run {run}: " + "; ".join(f"{c}: {d:.2e} ({k})" for c, (d, k) in sorted(line.items())), flush=True)
+print(f"worst run-to-run difference over all 1-D parameter gradients: {worst_1d}")
+assert worst_1d == 0.0, "a two-stage reduction is not reproducible"
