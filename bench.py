@@ -137,9 +137,16 @@ def other_work_fns():
         return {"tag": "spatial_attention_bwd", "flops": 10.0 * nseq * heads * n * n * dp,
                 "bytes": 2.0 * 8 * nseq * n * heads * dp}
 
+    def attn_hm_fwd(q, k, v, o, lse, bias, shift, nseq, n, heads, *rest):
+        return {"tag": "spatial_attention_fwd", "flops": 4.0 * nseq * heads * n * n * 32, "bytes": 2.0 * 4 * nseq * n * heads * 32}
+
+    def attn_hm_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, dbias, rel, dtable, tsize, gh, gw, nseq, n, heads, *rest):
+        return {"tag": "spatial_attention_bwd", "flops": 10.0 * nseq * heads * n * n * 32, "bytes": 2.0 * 8 * nseq * n * heads * 32}
+
     def vq(embed, x, pv, pi, ncodes, M, d, *rest):
         return {"tag": "vq_search", "flops": 2.0 * ncodes * M * d, "bytes": 2.0 * (M * d + ncodes * d) + 8.0 * 16 * M}
-    return {"patch_ln_fwd": patch_fwd, "attn_fwd": attn_fwd, "attn_bwd": attn_bwd, "vq_topk": vq}
+    return {"patch_ln_fwd": patch_fwd, "attn_fwd": attn_fwd, "attn_bwd": attn_bwd, "attn_hm_fwd": attn_hm_fwd,
+            "attn_hm_bwd": attn_hm_bwd, "vq_topk": vq}
 
 
 def patch_embed_chain(model, vol, reps=5):
@@ -398,6 +405,8 @@ def main():
     ap.add_argument("--text-len", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-attribution", action="store_true", help="skip the BASELINE configs[4] measurement (occlusion + IG)")
+    ap.add_argument("--lean", action="store_true", help="profiling runs: only warm-up + timed steps + the two single-stream "
+                    "steps (no event-timing A/B, no patch-embed chain, no attribution, no CPU baseline)")
     ap.add_argument("--local-negatives", action="store_true", help="BASELINE config 3: no embedding all-gather")
     ap.add_argument("--small", action="store_true", help="debug: 2+2-layer model on 64^3 volumes")
     args = ap.parse_args()
@@ -479,10 +488,10 @@ def main():
     # what the HIP-event pairs around the GEMM launches cost the timed region: the same steps once more with no timing armed
     sync()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(0 if args.lean else args.steps):
         trainer.train_step(batch)
     sync()
-    dt_plain = time.perf_counter() - t1
+    dt_plain = (time.perf_counter() - t1) if not args.lean else dt
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -498,14 +507,14 @@ def main():
         alone_tflops = alone["flops"] / (alone["total_ms"] * 1e-3) / 1e12 if alone["total_ms"] > 0 else 0.0
         kernels = {}
         tags = {}
-        for n in ("ctclip_patch_ln_fwd", "ctclip_attn_fwd", "ctclip_attn_bwd", "ctclip_vq_topk"):
+        for n in ("ctclip_patch_ln_fwd", "ctclip_attn_fwd", "ctclip_attn_bwd", "ctclip_attn_hm_fwd", "ctclip_attn_hm_bwd", "ctclip_vq_topk"):
             for ms, w in timed2.get(n, {}).get("items", []):
                 d = tags.setdefault(w["tag"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "extra_written": 0.0})
                 d["ms"] += ms; d["flops"] += w.get("flops", 0.0); d["bytes"] += w["bytes"]; d["launches"] += 1
                 d["extra_written"] += w.get("operand_bytes_written", 0.0)
         pmc_names = {"tubelet_gather_ln_fwd": ("patch_ln_fwd_fast",),
-                     "spatial_attention_fwd": ("ws_fwd_kernel",), "vq_search": ("vq_topk3_kernel",),
-                     "spatial_attention_bwd": ("ws_bwd_dq_kernel", "ws_bwd_dkv_kernel")}
+                     "spatial_attention_fwd": ("hm_fwd_kernel<true, true",), "vq_search": ("vq_topk3_kernel",),
+                     "spatial_attention_bwd": ("hm_bwd_dq_kernel", "hm_bwd_dkv_kernel")}
         for tag, d in tags.items():
             if d["ms"] <= 0:
                 continue
@@ -523,7 +532,7 @@ def main():
             hits = [[v for k, v in per_kernel_traffic.items() if k.startswith(pref)] for pref in pmc_names.get(tag, ())]
             ent["traffic"] = sum(h[0] for h in hits) if hits and all(hits) else None      # a call = one launch of each kernel named
             kernels[tag] = ent
-        if world == 1:
+        if world == 1 and not args.lean:
             kernels["patch_embed_fwd"] = patch_embed_chain(model, vol)
         # the whole step against HBM: counter traffic of every kernel of one step (same committed PMC passes) / the copy rate this
         # box sustains -- the step moves ~1.1 TB, so this, not the MFMA peak, is the bound the step as a whole runs against
@@ -579,11 +588,11 @@ def main():
                                  "puts the weight-gradient GEMMs on a second one); *_without_stream_overlap and `kernels`: same "
                                  "launches, two extra untimed steps on one stream; flops counted on the unpadded GEGLU width 1365"},
         }
-        if not args.no_attribution and world == 1 and not args.small:
+        if not args.no_attribution and not args.lean and world == 1 and not args.small:
             del batch
             torch.cuda.empty_cache()
             out["attribution"] = attribution_bench(model, vol, txt, dev)
-        if not args.no_cpu_baseline and world == 1 and not args.small:
+        if not args.no_cpu_baseline and not args.lean and world == 1 and not args.small:
             out["cpu_baseline"] = cpu_baseline(model, depth, size, args.text_len, text_cfg["vocab_size"])
         print(json.dumps(out), flush=True)
     if world > 1:

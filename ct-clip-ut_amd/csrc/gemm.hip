@@ -423,6 +423,9 @@ int ctclip_gemm2_launch(const void* A, const void* B, void* C, const float* bias
 int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                         long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                         hipStream_t st);
+int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
+                           long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
+                           int hm_n, int hm_heads, hipStream_t st);
 int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
                         float alpha, hipStream_t st);
 int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
@@ -483,6 +486,17 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
   g.split_k = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
   g.c_fp32 = c_fp32; g.atomic_out = accumulate ? 1 : 0; g.act = act; g.alpha = alpha;
   return launch<0>(g, a_kmajor, b_kmajor, (hipStream_t)stream);
+}
+
+// C = A[M,K] B[N,K]^T written as bf16 in the HEAD-MAJOR layout of attention_hm.hip: [part][sequence][head][token][32]
+// with token = row % n_tokens, sequence = row / n_tokens, head = (col / 32) % heads, part = col / (32 heads).
+// Always the 256 x 256 LDS-DMA kernel of gemm3.hip (its epilogue has the form): K % 32 == 0, N % 64 == 0, M % n_tokens == 0.
+int ctclip_gemm_bf16_headmajor(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, int n_tokens,
+                               int heads, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true) || (K % 32) || n_tokens <= 0) return (int)hipErrorInvalidValue;
+  return ctclip_gemm3_launch_hm(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, N, 0, 0, 1.0f, 0, nullptr, 0, n_tokens, heads,
+                                (hipStream_t)stream);
 }
 
 // scores[m][n] = sum_k A[m][k] B[n][k], never materialised; for every column n writes 16 candidates: the top-4 of each

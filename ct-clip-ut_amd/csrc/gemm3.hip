@@ -61,6 +61,13 @@ struct Args {
   bf16_t* G; long ldg;                             // EPI 2: gelu(gate) * value of the 32-column interleaved [val|gate] blocks
                                                    // EPI 3: G = h (pre-activations, same blocks), overwritten with d(h)
   int direct;                                      // pointers / strides allow the 16-byte register epilogue
+  // EPI 0, head-major output (hm_n > 0): column c = (part, head, d) with d = c % 32, head = (c / 32) % hm_heads, part =
+  // c / (32 hm_heads); row R = (sequence, token) with token = R % hm_n: element (R, c) goes to
+  //   C + part * hm_part + ((sequence * hm_heads + head) * hm_n + token) * 32 + d
+  // i.e. [part][sequence][head][token][32] -- the operand layout of attention_hm.hip.  hm_magic = ceil(2^32 / hm_n).
+  int hm_n, hm_heads;
+  uint32_t hm_magic;
+  long hm_part;
 };
 
 // [256 rows][32 k] bf16 tile, 64-byte rows, 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128 phase hit 16
@@ -503,13 +510,31 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
             for (int e = 0; e < 8; ++e) v[h][e] = gelu_erf(v[h][e]);
           }
         }
-        uint4 s0, s1;
-        line_pair(pack8(v[0]), pack8(v[1]), upper, s0, s1);
-        const int col = colw + 32 * hsel + 8 * q4;
-        const int row = rbase + i * 16 + rsub;
-        if (col < g.N) {
-          if (row < g.M) st16((bf16_t*)g.C + (long)row * g.ldc + col, s0);
-          if (row + 8 < g.M) st16((bf16_t*)g.C + (long)(row + 8) * g.ldc + col, s1);
+        if (g.hm_n) {
+          // head-major: the lane's two 16-byte pieces belong to two heads of ITS row; the 16 lanes of a row group write 16
+          // consecutive tokens x 64 bytes of one head = 1 KiB contiguous per store instruction -- whole lines as they stand
+          const int rowl = rbase + i * 16 + ml;
+          if (rowl < g.M) {
+            const uint32_t sq = __umulhi((uint32_t)rowl, g.hm_magic), tok = (uint32_t)rowl - sq * (uint32_t)g.hm_n;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int col = colw + 32 * h + 8 * q4;
+              if (col < g.N) {
+                const int vh = col >> 5, part = vh / g.hm_heads, hh = vh - part * g.hm_heads;
+                st16((bf16_t*)g.C + (long)part * g.hm_part + ((long)(sq * g.hm_heads + hh) * g.hm_n + tok) * 32 + 8 * q4,
+                     pack8(v[h]));
+              }
+            }
+          }
+        } else {
+          uint4 s0, s1;
+          line_pair(pack8(v[0]), pack8(v[1]), upper, s0, s1);
+          const int col = colw + 32 * hsel + 8 * q4;
+          const int row = rbase + i * 16 + rsub;
+          if (col < g.N) {
+            if (row < g.M) st16((bf16_t*)g.C + (long)row * g.ldc + col, s0);
+            if (row + 8 < g.M) st16((bf16_t*)g.C + (long)(row + 8) * g.ldc + col, s1);
+          }
         }
       }
     }
@@ -685,10 +710,23 @@ __global__ __launch_bounds__(512, 2) void vq_topk3_kernel(VqArgs g) {
 }  // namespace g3
 
 // called by ctclip_gemm_bf16 (gemm.hip): k-major x k-major, K % 32 == 0, plain (non-accumulating) output
+int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
+                           long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
+                           int hm_n, int hm_heads, hipStream_t st);
+
 int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                         long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                         hipStream_t st) {
+  return ctclip_gemm3_launch_hm(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, G, ldg, 0, 0, st);
+}
+
+// hm_n > 0: bf16 output in the head-major layout [part][sequence][head][token][32] (Args::hm_n); M % hm_n == 0, N % 64 == 0
+int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
+                           long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
+                           int hm_n, int hm_heads, hipStream_t st) {
   using namespace g3;
+  if (hm_n > 0 && (c_fp32 || act != 0 || hm_heads <= 0 || (M % hm_n) || (N & 63) || (N / 32) % hm_heads || (((uintptr_t)C) & 15)))
+    return (int)hipErrorInvalidValue;
   if (act < 0 || act > 3) return (int)hipErrorInvalidValue;
   if (act == 2 && (c_fp32 || bias || resid || !G || (N & 63) || (ldc & 7) || (ldg & 7) || (((uintptr_t)C) & 15) ||
                    (((uintptr_t)G) & 15)))
@@ -703,6 +741,12 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
   g.direct = (act >= 2) ||
              ((N & 7) == 0 && (((uintptr_t)C) & 15) == 0 && (ldc & (c_fp32 ? 3 : 7)) == 0 &&
               (!bias || (((uintptr_t)bias) & 15) == 0) && (!resid || ((((uintptr_t)resid) & 15) == 0 && (ldr & 3) == 0)));
+  if (hm_n > 0) {
+    if (!g.direct) return (int)hipErrorInvalidValue;
+    g.hm_n = hm_n; g.hm_heads = hm_heads;
+    g.hm_magic = (uint32_t)(((1ull << 32) + (unsigned long long)hm_n - 1) / (unsigned long long)hm_n);
+    g.hm_part = (long)M * hm_heads * 32;
+  }
   // shape: 256 x 256 (one workgroup per CU) everywhere but the f32-output products with a very short matrix loop (the
   // out-projection, K = 256: write-back-bound), where two 256 x 128 workgroups per CU overlap one's stores with the other's
   // loop.  CTCLIP_GEMM3_BN=128|256 forces one shape (experiments).

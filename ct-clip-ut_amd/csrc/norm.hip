@@ -179,13 +179,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
     prow[i] = (lnred[i] + lnred[2 * dim + i]) + (lnred[4 * dim + i] + lnred[6 * dim + i]);
 }
 
+// element offset of (row, head) in a [rows, ld] row-major matrix (hm_n == 0) or in the head-major layout
+// [sequence][head][token][D] of attention_hm.hip (hm_n = tokens per sequence)
+__device__ __forceinline__ long head_off(long row, int head, int H, int D, long ld, int hm_n) {
+  if (hm_n <= 0) return row * ld + (long)head * D;
+  const long sq = row / hm_n, tok = row - sq * hm_n;
+  return ((sq * H + head) * hm_n + tok) * D;
+}
+
 // ---- per-head cosine normalisation: y = x / max(|x|,1e-12) * scale[d] * mult --------------------
 // reference src/utils/attention.py:151-153 (+ the fixed `scale = 8` of :98,155 folded into q via mult)
 // LPH lanes share one (row, head); each lane owns 8 consecutive bf16 (16 bytes).  D = 8*LPH.
 template <int LPH>
 __global__ __launch_bounds__(256) void headnorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                            bf16_t* __restrict__ y, float* __restrict__ inv_norm,
-                                                           long npairs, int H, long ldx, long ldy, float mult) {
+                                                           long npairs, int H, long ldx, long ldy, float mult, int x_hm,
+                                                           int y_hm) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   const long pair = gid / LPH;
   const int sub = (int)(gid % LPH);
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(256) void headnorm_fwd_kernel(const bf16_t* __restr
   const int D = LPH * 8;
   float f[8];
   uint4 raw = make_uint4(0, 0, 0, 0);
-  if (ok) raw = *(const uint4*)(x + row * ldx + head * D + sub * 8);
+  if (ok) raw = *(const uint4*)(x + head_off(row, head, H, D, ldx, x_hm) + sub * 8);
   const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
   float ss = 0.f;
 #pragma unroll
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(256) void headnorm_fwd_kernel(const bf16_t* __restr
     const float s0 = scale[sub * 8 + 2 * i] * mult, s1 = scale[sub * 8 + 2 * i + 1] * mult;
     ow[i] = pack_bf16x2(f[2 * i] * inv * s0, f[2 * i + 1] * inv * s1);
   }
-  *(uint4*)(y + row * ldy + head * D + sub * 8) = o;
+  *(uint4*)(y + head_off(row, head, H, D, ldy, y_hm) + sub * 8) = o;
 }
 
 // dx = inv * (du - u (u . du)),  u = x*inv,  du = dy * scale * mult ;  dscale[d] += sum dy * u * mult
@@ -224,7 +233,8 @@ template <int LPH>
 __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                            const float* __restrict__ inv_norm, const float* __restrict__ scale,
                                                            bf16_t* __restrict__ dx, float* __restrict__ partials,
-                                                           long npairs, int H, long lddy, long ldx, long lddx, float mult) {
+                                                           long npairs, int H, long lddy, long ldx, long lddx, float mult,
+                                                           int x_hm) {
   __shared__ float red[256 / LPH][LPH * 8 + 1];                      // [pair slot of the workgroup][d]
   const int D = LPH * 8;
   const int sub = threadIdx.x % LPH;
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restr
     uint4 rx = make_uint4(0, 0, 0, 0), rd = make_uint4(0, 0, 0, 0);
     float inv = 0.f;
     if (ok) {
-      rx = *(const uint4*)(x + row * ldx + head * D + sub * 8);
+      rx = *(const uint4*)(x + head_off(row, head, H, D, ldx, x_hm) + sub * 8);
       rd = *(const uint4*)(dy + row * lddy + head * D + sub * 8);
       inv = inv_norm[pair];
     }
@@ -375,38 +385,39 @@ int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* 
 }
 
 int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_norm, long rows, int heads, int dhead,
-                        long ldx, long ldy, float mult, void* stream) {
+                        long ldx, long ldy, float mult, int x_hm_n, int y_hm_n, void* stream) {
   const long npairs = rows * heads;
   if (npairs <= 0) return 0;
   if (dhead != 32 && dhead != 64) return (int)hipErrorInvalidValue;
+  if ((x_hm_n > 0 && rows % x_hm_n) || (y_hm_n > 0 && rows % y_hm_n)) return (int)hipErrorInvalidValue;
   const int lph = dhead / 8;
   const long threads = npairs * lph;
   dim3 grid((unsigned)((threads + 255) / 256)), block(256);
   if (lph == 4)
     hipLaunchKernelGGL(headnorm_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, scale, (bf16_t*)y,
-                       inv_norm, npairs, heads, ldx, ldy, mult);
+                       inv_norm, npairs, heads, ldx, ldy, mult, x_hm_n, y_hm_n);
   else
     hipLaunchKernelGGL(headnorm_fwd_kernel<8>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, scale, (bf16_t*)y,
-                       inv_norm, npairs, heads, ldx, ldy, mult);
+                       inv_norm, npairs, heads, ldx, ldy, mult, x_hm_n, y_hm_n);
   CTCLIP_CHECK_LAUNCH();
 }
 
 int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
                         float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
-                        float* partials, void* stream) {
+                        int x_hm_n, float* partials, void* stream) {
   const long npairs = rows * heads;
   if (npairs <= 0) return 0;
-  if ((dhead != 32 && dhead != 64) || !partials) return (int)hipErrorInvalidValue;
+  if ((dhead != 32 && dhead != 64) || !partials || (x_hm_n > 0 && rows % x_hm_n)) return (int)hipErrorInvalidValue;
   const int lph = dhead / 8;
   long blocks = (npairs + (256 / lph) - 1) / (256 / lph);
   if (blocks > 2048) blocks = 2048;
   dim3 grid((unsigned)blocks), block(256);
   if (lph == 4)
     hipLaunchKernelGGL(headnorm_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
-                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult);
+                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n);
   else
     hipLaunchKernelGGL(headnorm_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
-                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult);
+                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return ctclip_reduce_partials(partials, (int)blocks, dhead, dhead, dscale, (hipStream_t)stream);

@@ -402,11 +402,27 @@ class PegFn(Function):
 # ---------------------------------------------------------------------------------------------------
 # Attention block: LN -> q / kv projections -> cosine-sim attention -> out projection (+ residual)
 # ---------------------------------------------------------------------------------------------------
+LOG2E = 1.4426950408889634
+LN2 = 0.6931471805599453
+
+
+def attn_head_major_ok(n, dh, dp, dim, want_probs):
+    """Shapes the head-major spatial-attention kernels (csrc/attention_hm.hip) take: d_head 32, whole 32-token tiles, at most
+    20 of them (the d(bias) tiles of a query block and the wave images fill the LDS), and nobody asking for the
+    probabilities."""
+    return dh == dp == 32 and n % 32 == 0 and 1 <= n // 32 <= 20 and dim % 32 == 0 and not want_probs
+
+
 class AttentionFn(Function):
     """attention.py:126-182 for self-attention without null-kv / mask / causal (the CT-ViT configuration).
 
     bias_t is the autograd-visible bias input: None, a dense [heads,n,n] tensor, or (table mode) the
-    [R, heads] position table whose dense expansion / index map come in `aux`."""
+    [R, heads] position table whose dense expansion / index map come in `aux`.
+
+    Logits live in the log2 domain on every path: head-norm multiplies q by scale * log2(e) and the attention kernels are
+    told scale = ln 2 (natural logit = ln2 * q.k + bias), so no kernel multiplies a score tile by a constant.  Shapes
+    attn_head_major_ok() accepts run on head-major q / k / v / dO ([sequence][head][token][32], written that way by
+    head-norm and by the kv / out-projection-gradient GEMM epilogues) with the static softmax shift of ctclip_attn_shift."""
 
     @staticmethod
     def forward(ctx, x, gamma, wq, wkv, q_scale, k_scale, wout, bias_t, sh, cfg, aux):
@@ -414,37 +430,57 @@ class AttentionFn(Function):
         nseq, n, dim = x.shape
         M = nseq * n
         inner = heads * dp
+        dev = x.device
+        hm = attn_head_major_ok(n, dh, dp, dim, want_probs)
+        qmult = float(scale) * LOG2E
         x2 = _c(x).reshape(M, dim)
         n1, _, mean, rstd = layernorm(x2, gamma.detach(), None, 1e-5)
         x16 = aux.get("x16")
         xb = x16.reshape(M, dim) if (x16 is not None and x16.numel() == M * dim and x16.is_contiguous()) else cast16(x2)
         q = gemm(n1, sh["wq"], M, inner, dim)
-        kv = gemm(xb, sh["wkv"], M, 2 * inner, dim)               # QUIRK attention.py:138: kv from un-normalised x
-        qh = torch.empty_like(q)
-        kh = torch.empty(M, inner, dtype=BF16, device=x.device)
-        qinv = torch.empty(M, heads, dtype=F32, device=x.device)
-        kinv = torch.empty(M, heads, dtype=F32, device=x.device)
-        hip.headnorm_fwd(q, sh["q_scale"], qh, qinv, M, heads, dp, inner, inner, float(scale))
-        hip.headnorm_fwd(kv, sh["k_scale"], kh, kinv, M, heads, dp, 2 * inner, inner, 1.0)
-        o = torch.empty(M, inner, dtype=BF16, device=x.device)
-        lse = torch.empty(nseq, heads, n, dtype=F32, device=x.device)
+        qinv = torch.empty(M, heads, dtype=F32, device=dev)
+        kinv = torch.empty(M, heads, dtype=F32, device=dev)
+        o = torch.empty(M, inner, dtype=BF16, device=dev)
+        lse = torch.empty(nseq, heads, n, dtype=F32, device=dev)
         kind = aux["kind"]                                        # None | "dense" | "table"
         bias_dense = None
         if kind == "dense":
             bias_dense = _c(bias_t.detach().to(F32))
         elif kind == "table":
             bias_dense = aux["dense"]
-        hip.attn_fwd(qh, kh, kv[:, inner:], o, lse, bias_dense, None, nseq, n, heads, dp, inner, inner, 2 * inner,
-                     inner, 1.0)
+        if hm:
+            kv = torch.empty(2, nseq, heads, n, dp, dtype=BF16, device=dev)          # QUIRK attention.py:138: kv from un-normalised x
+            hip.gemm_bf16_headmajor(xb, sh["wkv"], kv, M, 2 * inner, dim, xb.stride(0), sh["wkv"].stride(0), n, heads)
+            qh = torch.empty(nseq, heads, n, dp, dtype=BF16, device=dev)
+            kh = torch.empty(nseq, heads, n, dp, dtype=BF16, device=dev)
+            hip.headnorm_fwd(q, sh["q_scale"], qh, qinv, M, heads, dp, inner, 0, qmult, 0, n)
+            hip.headnorm_fwd(kv[0], sh["k_scale"], kh, kinv, M, heads, dp, 0, 0, 1.0, n, n)
+            shift = torch.empty(heads + 1, dtype=F32, device=dev)
+            if kind == "table":
+                tb = bias_t.detach()
+                hip.attn_shift(sh["q_scale"], sh["k_scale"], dp, qmult, tb, tb.shape[0], 1, tb.stride(0), heads, shift)
+            elif kind == "dense":
+                hip.attn_shift(sh["q_scale"], sh["k_scale"], dp, qmult, bias_dense, n * n, n * n, 1, heads, shift)
+            else:
+                hip.attn_shift(sh["q_scale"], sh["k_scale"], dp, qmult, None, 0, 0, 0, heads, shift)
+            hip.attn_hm_fwd(qh, kh, kv[1], o, lse, bias_dense, shift, nseq, n, heads, inner)
+        else:
+            kv = gemm(xb, sh["wkv"], M, 2 * inner, dim)           # QUIRK attention.py:138: kv from un-normalised x
+            qh = torch.empty_like(q)
+            kh = torch.empty(M, inner, dtype=BF16, device=dev)
+            hip.headnorm_fwd(q, sh["q_scale"], qh, qinv, M, heads, dp, inner, inner, qmult, 0, 0)
+            hip.headnorm_fwd(kv, sh["k_scale"], kh, kinv, M, heads, dp, 2 * inner, inner, 1.0, 0, 0)
+            hip.attn_fwd(qh, kh, kv[:, inner:], o, lse, bias_dense, None, nseq, n, heads, dp, inner, inner, 2 * inner,
+                         inner, LN2)
         y = gemm(o, sh["wout"], M, dim, inner, out_dtype=F32, resid=x2 if residual else None)
         if want_probs:
-            probs = torch.empty(nseq, heads, n, n, dtype=F32, device=x.device)
-            hip.attn_probs(qh, kh, lse, bias_dense, None, probs, nseq, n, heads, dp, inner, inner, 1.0)
+            probs = torch.empty(nseq, heads, n, n, dtype=F32, device=dev)
+            hip.attn_probs(qh, kh, lse, bias_dense, None, probs, nseq, n, heads, dp, inner, inner, LN2)
         else:
             probs = x.new_empty(0)
         ctx.save_for_backward(x2, gamma, mean, rstd, n1, xb, q, kv, qh, kh, qinv, kinv, o, lse,
                               bias_dense if bias_dense is not None else x2.new_empty(0))
-        ctx.sh, ctx.cfg, ctx.aux, ctx.shape = sh, cfg, aux, (nseq, n, dim)
+        ctx.sh, ctx.cfg, ctx.aux, ctx.shape, ctx.hm = sh, cfg, aux, (nseq, n, dim), hm
         ctx.params = (gamma, wq, wkv, q_scale, k_scale, wout)
         ctx.mark_non_differentiable(probs)
         return y.reshape(nseq, n, dim), probs
@@ -453,17 +489,17 @@ class AttentionFn(Function):
     @announces
     def backward(ctx, dy, _dprobs):
         x2, gamma, mean, rstd, n1, xb, q, kv, qh, kh, qinv, kinv, o, lse, bias_dense = ctx.saved_tensors
-        sh, aux = ctx.sh, ctx.aux
+        sh, aux, hm = ctx.sh, ctx.aux, ctx.hm
         heads, dh, dp, scale, residual, _ = ctx.cfg
         nseq, n, dim = ctx.shape
         M, inner = nseq * n, heads * dp
         dev = dy.device
         kind = aux["kind"]
+        qmult = float(scale) * LOG2E
         if bias_dense.numel() == 0:
             bias_dense = None
         dy2 = _c(dy).reshape(M, dim)
         dyb = _get16(dy)
-        do = dgrad(dyb, sh["wout"], M, dim, inner, out_dtype=BF16, wT16=sh.get("woutT"))
         dqh = torch.empty(M, inner, dtype=BF16, device=dev)
         dkh = torch.empty(M, inner, dtype=BF16, device=dev)
         dkv = torch.empty(M, 2 * inner, dtype=BF16, device=dev)
@@ -477,9 +513,18 @@ class AttentionFn(Function):
             dtable = torch.zeros(heads, tsize, dtype=F32, device=dev)
             gh, gw = aux.get("grid", (0, 0))
             rel = None if gw else aux["relidx"]
-        hip.attn_bwd(qh, kh, kv[:, inner:], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, None,
-                     dbias_dense, rel, dtable, tsize, gh, gw, nseq, n, heads, dp,
-                     inner, inner, 2 * inner, inner, inner, inner, inner, 2 * inner, 1.0)
+        if hm:
+            # d(o) = dy Wout as a k-major x k-major product with the transposed weight shadow, written head-major
+            do = torch.empty(nseq, heads, n, dp, dtype=BF16, device=dev)
+            hip.gemm_bf16_headmajor(dyb, sh["woutT"], do, M, inner, dim, dyb.stride(0), sh["woutT"].stride(0), n, heads)
+            hip.attn_hm_bwd(qh, kh, kv[1], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, dbias_dense, rel, dtable,
+                            tsize, gh, gw, nseq, n, heads, inner, inner, inner, 2 * inner)
+        else:
+            do = dgrad(dyb, sh["wout"], M, dim, inner, out_dtype=BF16, wT16=sh.get("woutT"))
+            hip.attn_bwd(qh, kh, kv[:, inner:], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, None,
+                         dbias_dense, rel, dtable, tsize, gh, gw, nseq, n, heads, dp,
+                         inner, inner, 2 * inner, inner, inner, inner, inner, 2 * inner, LN2)
+        k_raw, k_ld, k_hm = (kv[0], 0, n) if hm else (kv, 2 * inner, 0)
         p_gamma, p_wq, p_wkv, p_qs, p_ks, p_wout = ctx.params
         dq = torch.empty(M, inner, dtype=BF16, device=dev)
         dbias = None
@@ -496,8 +541,8 @@ class AttentionFn(Function):
             gwo, d5 = grad_slot(p_wout)
             gg, d6 = grad_slot(p_gamma)
             wgrad(dyb, o, dim, inner, M, out=gwo)
-            hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, inner, inner, float(scale))
-            hip.headnorm_bwd(dkh, kv, kinv, sh["k_scale"], dkv, gks, M, heads, dp, inner, 2 * inner, 2 * inner, 1.0)
+            hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, inner, inner, qmult, 0)
+            hip.headnorm_bwd(dkh, k_raw, kinv, sh["k_scale"], dkv, gks, M, heads, dp, inner, k_ld, 2 * inner, 1.0, k_hm)
             # both data gradients leave their (store-bound, K = 256 / 512) GEMMs in bf16; the f32 residual-path gradient
             # dy2 is added inside the LayerNorm backward, so the residual stream itself never passes through bf16
             dn1 = dgrad(dq, sh["wq"], M, inner, dim, out_dtype=BF16, wT16=sh.get("wqT"))
@@ -514,8 +559,8 @@ class AttentionFn(Function):
         dwout = wgrad(dyb, o, dim, inner, M)
         dqs = torch.zeros(dp, dtype=F32, device=dev)
         dks = torch.zeros(dp, dtype=F32, device=dev)
-        hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, dqs, M, heads, dp, inner, inner, inner, float(scale))
-        hip.headnorm_bwd(dkh, kv, kinv, sh["k_scale"], dkv, dks, M, heads, dp, inner, 2 * inner, 2 * inner, 1.0)
+        hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, dqs, M, heads, dp, inner, inner, inner, qmult, 0)
+        hip.headnorm_bwd(dkh, kv, kinv, sh["k_scale"], dkv, dks, M, heads, dp, inner, 2 * inner, 2 * inner, 1.0, 0)
         dn1 = dgrad(dq, sh["wq"], M, inner, dim, wT16=sh.get("wqT"))
         dwq = wgrad(dq, n1, inner, dim, M)
         dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None, wT16=sh.get("wkvT"))

@@ -397,6 +397,7 @@ class GradSync:
                 h.wait()
         b["handle"] = None
         b["pending"] = b["n"]
+        b["seen"] = set()
 
     def before_write(self, param):
         """`param`'s arena slot is about to be written by gradient kernels that have NOT been issued yet."""
@@ -415,6 +416,10 @@ class GradSync:
         b = self._bucket_of.get(id(param))
         if b is None or b["handle"] is not None:
             return
+        seen = b.setdefault("seen", set())
+        if id(param) in seen:                                # the engine also runs the post-accumulate hook of a parameter
+            return                                           # whose Function accumulated in place and returned None
+        seen.add(id(param))
         b["pending"] -= 1
         if b["pending"] <= 0:
             self._launch(b)

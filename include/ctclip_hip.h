@@ -87,12 +87,14 @@ int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* 
                               const float* dres, const void* dres2_bf16, float* dx, void* dx_bf16, float* dgamma,
                               float* dbeta, int rows, int dim, float* partials, void* stream);
 
-/* ---- per-head cosine normalisation: y = x/|x| * scale[d] * mult   (attention.py:151-153,155) ---- */
+/* ---- per-head cosine normalisation: y = x/|x| * scale[d] * mult   (attention.py:151-153,155) ----
+ * x_hm_n / y_hm_n > 0: that operand is in the HEAD-MAJOR layout [sequence][head][token][dhead] with x_hm_n tokens per
+ * sequence (rows % x_hm_n == 0; its ld is ignored) -- the operand layout of ctclip_attn_hm_*; 0: row-major [rows, ld]. */
 int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_norm, long rows, int heads, int dhead,
-                        long ldx, long ldy, float mult, void* stream);
+                        long ldx, long ldy, float mult, int x_hm_n, int y_hm_n, void* stream);
 int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
                         float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
-                        float* partials, void* stream);
+                        int x_hm_n, float* partials, void* stream);
 
 /* ---- fused attention (attention.py:155-180; BertSelfAttention) ----------------------------------
  * q,k,v,o: [nseq*n, ld] bf16, head h in columns h*dhead.. ; dhead in {32,64}.
@@ -122,6 +124,30 @@ int ctclip_attn_bwd_dropout(const void* q, const void* k, const void* v, const v
                             float* dbias_table, int table_size, int grid_h, int grid_w, int nseq, int n, int heads, int dhead,
                             long ldq, long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, float scale,
                             void* stream);
+/* ---- the same attention on HEAD-MAJOR operands (csrc/attention_hm.hip): the CT-ViT's spatial attention, attention.py:146-182
+ * at n = 576, d_head = 32 with the relative-position bias shared by all sequences.
+ *   q, k, v, dO: bf16 [nseq][heads][n][32] (written by ctclip_headnorm_fwd / ctclip_gemm_bf16_headmajor);
+ *   o, dq, dk, dv: bf16 row-major [nseq * n, ld], head h in columns 32 h ..;  lse, delta: [nseq, heads, n] f32.
+ * LOG2 DOMAIN: the caller has folded scale * log2(e) into q (head-norm's `mult`), so the natural logit is
+ *   ln(2) * (q . k) + bias[h][i][j]   and   P = softmax of it;   dq, dk are the gradients w.r.t. the q, k GIVEN.
+ * shift (forward, optional): [heads + 1] floats from ctclip_attn_shift -- per head a bound B_h on every |log2-logit| (a
+ * function of q_scale, k_scale and the bias alone), and a flag.  While B_h <= 60 binades the softmax needs no maximum at all
+ * (p = 2^s stays inside f32 / bf16 range, sums in f32); when the flag says the bound is wider, the online-softmax kernel of
+ * the same launch pair runs instead (both are enqueued, one returns at once: no host synchronisation).
+ * n % 32 == 0, n <= 768 (n <= 640 when a bias gradient is asked for: hipErrorInvalidValue beyond); d(bias) as ctclip_attn_bwd (dense, or the [heads][table_size] table). */
+int ctclip_attn_shift(const float* q_scale, const float* k_scale, int dhead, float qk_mult, const float* bias, long bias_count,
+                      long bias_head_stride, long bias_elem_stride, int heads, float* shift, void* stream);
+int ctclip_attn_hm_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
+                       const float* shift, int nseq, int n, int heads, long ldo, void* stream);
+int ctclip_attn_hm_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
+                       float* delta, void* dq, void* dk, void* dv, const float* bias, float* dbias_dense,
+                       const uint16_t* relidx, float* dbias_table, int table_size, int grid_h, int grid_w, int nseq, int n,
+                       int heads, long ldo, long lddq, long lddk, long lddv, void* stream);
+/* C = A[M,K] B[N,K]^T (both k-major, K % 32 == 0, N % 64 == 0) written as bf16 in that head-major layout:
+ * [part][sequence][head][token][32], token = row % n_tokens, head = (col / 32) % heads, part = col / (32 heads)
+ * (the K/V projection attention.py:119,142 has two parts; the out-projection's data gradient one). */
+int ctclip_gemm_bf16_headmajor(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, int n_tokens,
+                               int heads, void* stream);
 /* probabilities [nseq,heads,n,n] f32, for callers that want Attention.forward's second output */
 int ctclip_attn_probs(const void* q, const void* k, const float* lse, const float* bias, const float* mask,
                       float* probs, int nseq, int n, int heads, int dhead, long ldq, long ldk, float scale,

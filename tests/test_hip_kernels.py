@@ -390,13 +390,13 @@ def test_headnorm_fwd_bwd(hip, D):
     ref = torch.nn.functional.normalize(xr, dim=-1) * scr * mult
     y = torch.empty(rows, H * D, device=DEV, dtype=torch.bfloat16)
     inv = torch.empty(rows, H, device=DEV)
-    hip.headnorm_fwd(x, sc, y, inv, rows, H, D, x.stride(0), H * D, mult)
+    hip.headnorm_fwd(x, sc, y, inv, rows, H, D, x.stride(0), H * D, mult, 0, 0)
     check("headnorm y", y.float().reshape(rows, H, D), ref, 1e-2)
     dy = bf(rnd(rows, H * D, seed=16))
     ref.backward(dy.float().reshape(rows, H, D))
     dx = torch.empty(rows, H * D, device=DEV, dtype=torch.bfloat16)
     ds = torch.zeros(D, device=DEV)
-    hip.headnorm_bwd(dy, x, inv, sc, dx, ds, rows, H, D, H * D, x.stride(0), H * D, mult)
+    hip.headnorm_bwd(dy, x, inv, sc, dx, ds, rows, H, D, H * D, x.stride(0), H * D, mult, 0)
     check("headnorm dx", dx.float().reshape(rows, H, D), xr.grad, 1e-2)
     check("headnorm dscale", ds, scr.grad, 1e-3)
 
@@ -534,6 +534,145 @@ def test_spatial_attention_bias_gradient_under_lds_locks_is_reproducible(hip):
     rel = (ii[:, None] // gw - ii[None] // gw + gh - 1) * (2 * gw - 1) + (ii[:, None] % gw - ii[None] % gw + gw - 1)
     ref = torch.zeros(H, R, device=DEV).index_add_(1, rel.reshape(-1), dense.reshape(H, -1))
     check("table vs scattered dense d(bias)", runs[0][0], ref, 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- head-major spatial attention
+def to_hm(t, nseq, n, H, D):
+    """row-major [nseq * n, H * D] -> head-major [nseq, H, n, D]"""
+    return t.reshape(nseq, n, H, D).permute(0, 2, 1, 3).contiguous()
+
+
+def test_headnorm_and_gemm_write_head_major(hip):
+    """The producers of the head-major operands: ctclip_headnorm_fwd / _bwd with x_hm_n / y_hm_n, and
+    ctclip_gemm_bf16_headmajor (the kv projection's two parts; a ragged last row tile), against the row-major forms."""
+    nseq, n, H, D, K = 3, 96, 4, 32, 64
+    rows = nseq * n
+    x = bf(rnd(rows, H * D, seed=90))
+    sc = 1 + 0.3 * rnd(D, seed=91)
+    y_rm, inv_rm = torch.empty_like(x), torch.empty(rows, H, device=DEV)
+    hip.headnorm_fwd(x, sc, y_rm, inv_rm, rows, H, D, H * D, H * D, 8.0, 0, 0)
+    y_hm, inv = torch.empty(nseq, H, n, D, device=DEV, dtype=torch.bfloat16), torch.empty(rows, H, device=DEV)
+    hip.headnorm_fwd(x, sc, y_hm, inv, rows, H, D, H * D, 0, 8.0, 0, n)             # row-major in, head-major out
+    assert torch.equal(y_hm, to_hm(y_rm, nseq, n, H, D)) and torch.equal(inv, inv_rm)
+    x_hm = to_hm(x, nseq, n, H, D)
+    y2 = torch.empty_like(y_hm)
+    hip.headnorm_fwd(x_hm, sc, y2, inv, rows, H, D, 0, 0, 8.0, n, n)                 # head-major in and out
+    assert torch.equal(y2, y_hm)
+    dy = bf(rnd(rows, H * D, seed=92))
+    dx_rm, ds_rm = torch.empty_like(x), torch.zeros(D, device=DEV)
+    hip.headnorm_bwd(dy, x, inv_rm, sc, dx_rm, ds_rm, rows, H, D, H * D, H * D, H * D, 8.0, 0)
+    dx2, ds2 = torch.empty_like(x), torch.zeros(D, device=DEV)
+    hip.headnorm_bwd(dy, x_hm, inv_rm, sc, dx2, ds2, rows, H, D, H * D, 0, H * D, 8.0, n)   # x head-major
+    assert torch.equal(dx2, dx_rm) and torch.equal(ds2, ds_rm)
+    # GEMM: M = 288 rows (one full 256-row tile + a ragged one), N = 2 parts x 4 heads x 32
+    A, B = bf(rnd(rows, K, seed=93)), bf(rnd(2 * H * D, K, seed=94))
+    C_rm = torch.empty(rows, 2 * H * D, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16(A, B, C_rm, None, None, rows, 2 * H * D, K, K, K, 2 * H * D, 0, 1, 1, 0, 1, 0, 1.0, 0)
+    C_hm = torch.full((2, nseq, H, n, D), 7.0, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16_headmajor(A, B, C_hm, rows, 2 * H * D, K, K, K, n, H)
+    want = torch.stack((to_hm(C_rm[:, : H * D], nseq, n, H, D), to_hm(C_rm[:, H * D:], nseq, n, H, D)))
+    check("head-major GEMM output", C_hm, want.float(), 1e-2)
+    assert torch.equal(C_hm, want)                                            # same kernel, same arithmetic: only the addresses differ
+
+
+@pytest.mark.parametrize("nseq,n,H,use_bias,chunk", [
+    (5, 64, 2, True, 0),        # two tiles, one query-block group
+    (12, 576, 8, True, 0),      # the CT-ViT spatial shape: 18 tiles, nine groups of two query blocks
+    (7, 160, 3, True, 3),       # 5 tiles: a half-empty last group; three sequences per workgroup + a ragged last chunk
+    (4, 96, 4, False, 0),       # no bias
+    (3, 640, 1, True, 0),       # 20 tiles: the d(bias) pass has room for 8 waves only
+])
+def test_head_major_attention_fwd_bwd(hip, nseq, n, H, use_bias, chunk, monkeypatch):
+    """ctclip_attn_hm_fwd / _bwd (csrc/attention_hm.hip) against f32 torch on the same bf16-rounded operands: log2-domain
+    logits (q carries scale * log2 e, natural logit = ln2 * q.k + bias), no-maximum softmax under ctclip_attn_shift's bound, bias
+    through the f16 identity MFMA, out / lse / dq / dk / dv and d(bias) in its dense, index-table and 2-D grid forms.
+    Also: the online-softmax kernel of the launch pair (no shift, and a shift flagged unsafe) gives the same result."""
+    D, LOG2E, LN2 = 32, 1.4426950408889634, 0.6931471805599453
+    if chunk:
+        monkeypatch.setenv("CTCLIP_ATTN_SP_CHUNK", str(chunk))
+    ld = H * D
+    qs, ks = 1 + 0.2 * rnd(D, seed=101), 1 + 0.2 * rnd(D, seed=102)
+    unit = lambda t: torch.nn.functional.normalize(t.reshape(nseq * n, H, D), dim=-1)
+    qmult = 8.0 * LOG2E
+    q = bf((unit(rnd(nseq * n, ld, seed=103)) * qs * qmult).reshape(nseq * n, ld))
+    k = bf((unit(rnd(nseq * n, ld, seed=104)) * ks).reshape(nseq * n, ld))
+    v, do = bf(rnd(nseq * n, ld, seed=105)), bf(rnd(nseq * n, ld, seed=106))
+    bias = 1.5 * rnd(H, n, n, seed=107) if use_bias else None
+    sp = lambda t: t.float().reshape(nseq, n, H, D).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+    qr, kr, vr = sp(q), sp(k), sp(v)
+    br = bias.clone().requires_grad_(True) if use_bias else None
+    oref, _ = attn_ref(qr, kr, vr, br, None, LN2)
+    lse_ref = torch.logsumexp(torch.einsum("shid,shjd->shij", qr, kr).detach() * LN2 + (bias[None] if use_bias else 0.0), dim=-1)
+    q_hm, k_hm, v_hm, do_hm = (to_hm(t, nseq, n, H, D) for t in (q, k, v, do))
+    shift = torch.empty(H + 1, device=DEV)
+    if use_bias:
+        hip.attn_shift(qs, ks, D, qmult, bias, n * n, n * n, 1, H, shift)
+    else:
+        hip.attn_shift(qs, ks, D, qmult, None, 0, 0, 0, H, shift)
+    assert float(shift[H]) == 0.0                                          # the bound fits f32 with room to spare
+    smax = (torch.einsum("shid,shjd->shij", qr, kr).detach() + (bias[None] * LOG2E if use_bias else 0.0)).abs().amax(dim=(0, 2, 3))
+    assert bool((shift[:H] >= smax).all()), "ctclip_attn_shift is not a bound of the |log2-logits|"
+    o = torch.empty(nseq * n, ld, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(nseq, H, n, device=DEV)
+    hip.attn_hm_fwd(q_hm, k_hm, v_hm, o, lse, bias, shift, nseq, n, H, ld)
+    un = lambda t: t.float().reshape(nseq, n, H, D).permute(0, 2, 1, 3)
+    check("hm attn out (bounded logits, no maximum)", un(o), oref, 2e-2)
+    check("hm attn lse", lse, lse_ref, 2e-3)
+    for label, sh_arg in (("no shift given", None), ("shift flagged unsafe", torch.cat((shift[:H], torch.ones(1, device=DEV))))):
+        o2, lse2 = torch.full_like(o, 3.0), torch.empty_like(lse)
+        hip.attn_hm_fwd(q_hm, k_hm, v_hm, o2, lse2, bias, sh_arg, nseq, n, H, ld)
+        check(f"hm attn out (online softmax: {label})", un(o2), oref, 2e-2)
+        check(f"hm attn lse (online softmax: {label})", lse2, lse_ref, 2e-3)
+        check("static vs online out", o2, o.float(), 1e-2)
+
+    oref.backward(do.float().reshape(nseq, n, H, D).permute(0, 2, 1, 3))
+    dq, dk, dv = (torch.empty(nseq * n, ld, device=DEV, dtype=torch.bfloat16) for _ in range(3))
+    delta = torch.empty(nseq, H, n, device=DEV)
+    hip.attn_hm_bwd(q_hm, k_hm, v_hm, o, do_hm, lse, delta, dq, dk, dv, bias, None, None, None, 0, 0, 0, nseq, n, H,
+                    ld, ld, ld, ld)
+    check("hm attn dq", un(dq), qr.grad, 3e-2)
+    check("hm attn dk", un(dk), kr.grad, 3e-2)
+    check("hm attn dv", un(dv), vr.grad, 3e-2)
+    check("hm attn delta", delta, (un(do) * un(o)).sum(-1), 2e-2)
+    if not use_bias:
+        return
+    dq0, dk0, dv0 = dq.clone(), dk.clone(), dv.clone()
+    dense = torch.zeros(H, n, n, device=DEV)
+    hip.attn_hm_bwd(q_hm, k_hm, v_hm, o, do_hm, lse, delta, dq, dk, dv, bias, dense, None, None, 0, 0, 0, nseq, n, H,
+                    ld, ld, ld, ld)
+    check("hm attn dbias dense", dense, br.grad, 3e-2)
+    check("hm attn dq (d(bias) pass)", un(dq), qr.grad, 3e-2)
+    assert torch.equal(dk, dk0) and torch.equal(dv, dv0)
+    R = 37
+    relidx = torch.randint(0, R, (n, n), generator=torch.Generator().manual_seed(3)).to(DEV)
+    dt = torch.zeros(H, R, device=DEV)
+    hip.attn_hm_bwd(q_hm, k_hm, v_hm, o, do_hm, lse, delta, dq, dk, dv, bias, None, relidx.to(torch.uint16), dt, R, 0, 0,
+                    nseq, n, H, ld, ld, ld, ld)
+    check("hm attn dbias table", dt, torch.zeros(H, R, device=DEV).index_add_(1, relidx.reshape(-1), br.grad.reshape(H, -1)), 3e-2)
+    gh = next(d for d in (24, 8, 5, 4, 3, 2, 1) if n % d == 0)
+    gw = n // gh
+    ii = torch.arange(n, device=DEV)
+    rel2 = ((ii[:, None] // gw - ii[None] // gw + gh - 1) * (2 * gw - 1) + (ii[:, None] % gw - ii[None] % gw + gw - 1))
+    R2 = (2 * gh - 1) * (2 * gw - 1)
+    dt2 = torch.zeros(H, R2, device=DEV)
+    hip.attn_hm_bwd(q_hm, k_hm, v_hm, o, do_hm, lse, delta, dq, dk, dv, bias, None, None, dt2, R2, gh, gw, nseq, n, H,
+                    ld, ld, ld, ld)
+    check("hm attn dbias 2-D grid table", dt2, torch.zeros(H, R2, device=DEV).index_add_(1, rel2.reshape(-1), br.grad.reshape(H, -1)), 3e-2)
+
+
+def test_attention_shift_flags_wide_bounds(hip):
+    """ctclip_attn_shift: learned scales far beyond initialisation (2 * qk bound + bias range > 100 binades) set the flag
+    that sends the launch pair to the online-softmax kernel."""
+    D, H = 32, 2
+    shift = torch.empty(H + 1, device=DEV)
+    ones = torch.ones(D, device=DEV)
+    table = rnd(50, H, seed=110)                                            # [R, heads]: element stride = heads
+    hip.attn_shift(ones, ones, D, 8.0 * 1.4426950408889634, table, 50, 1, H, H, shift)
+    assert float(shift[H]) == 0.0
+    want = 8.0 * 1.4426950408889634 * 1.02 + 0.25 + table.abs().amax(0) * 1.4426950408889634
+    check("shift from a [R, heads] table", shift[:H], want, 1e-6)
+    hip.attn_shift(ones * 3.0, ones * 2.0, D, 8.0 * 1.4426950408889634, table, 50, 1, H, H, shift)   # qk bound ~71 binades
+    assert float(shift[H]) == 1.0
 
 
 # ---------------------------------------------------------------------------------------------- dropout (text encoder)
@@ -767,9 +906,9 @@ def test_two_stage_reductions_are_bitwise_reproducible(hip):
         q, dq = bf(rnd(rows, H * D, seed=74)), bf(rnd(rows, H * D, seed=75))
         sc = 1 + 0.1 * rnd(D, seed=76)
         qn, inv = torch.empty_like(q), torch.empty(rows, H, device=DEV)
-        hip.headnorm_fwd(q, sc, qn, inv, rows, H, D, H * D, H * D, 8.0)
+        hip.headnorm_fwd(q, sc, qn, inv, rows, H, D, H * D, H * D, 8.0, 0, 0)
         dxh, ds = torch.empty_like(q), torch.zeros(D, device=DEV)
-        hip.headnorm_bwd(dq, q, inv, sc, dxh, ds, rows, H, D, H * D, H * D, H * D, 8.0)
+        hip.headnorm_bwd(dq, q, inv, sc, dxh, ds, rows, H, D, H * D, H * D, H * D, 8.0, 0)
         out["headnorm dscale"] = ds
         cs = torch.zeros(dim, device=DEV)
         hip.colsum_accum(dy, 0, rows, dim, dim, cs)
