@@ -25,6 +25,13 @@
 //      MFMA, in the dK/dV pass (constant per accumulator row) loaded from LDS straight into the accumulator registers --
 //      so p = exp2(S') and dS = p * dP'.
 // Per score tile and wave the forward now issues 16 v_exp, 16 v_add (row sum), 8 v_cvt_pk and 6 MFMAs (4 without a bias).
+// Where the forward stands (1536 x 8 x 576 x 32, profiles/r03_attention_pmc.txt): 1.11 ms = 470 TFLOP/s; the SQ counters give
+// 51.5 VALU instructions and 6 MFMAs per score tile = 270 + 192 cycles of issue per tile and SIMD-resident wave pair, i.e.
+// VALU 47 % + matrix pipe 33 % of all SIMD cycles -- the two pipes of a SIMD are shared by its two waves and an MFMA holds
+// the vector issue port for 8 of its 32 cycles, so this is close to what two waves per SIMD can interleave.  Measured and
+// dropped on the way: 12 waves per workgroup (three per SIMD: 168 registers, 14 spilled: 1275 us), one query block per
+// wave with 16 or 12 waves (K / V fetched twice as often: 1437 / 1412 us), touching the wave's next sequence in L2 one
+// sequence ahead (1137 us: the first touch is not what the tiles wait for).
 #include "attn_common.h"
 
 namespace {

@@ -211,10 +211,22 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   __shared__ float red[LANES][CPB + 1];
   const int cl = threadIdx.x % CPB, rl = threadIdx.x / CPB;
   const int c = blockIdx.x * CPB + cl;
-  float s = 0.f;
-  if (c < width)
-    for (int b = rl; b < nparts; b += LANES) s += partials[(long)b * ld + c];
-  red[rl][cl] = s;
+  // four independent chains per row lane (rows rl, rl + LANES, ... taken round-robin): the loads of a chain do not wait for
+  // each other's adds -- the kernel is pure latency otherwise (a few microseconds for a sum of a few megabytes, ~190 of them
+  // per training step); the association ((a0 + a1) + (a2 + a3)) is fixed, so the result stays reproducible
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < width) {
+    const float* p = partials + c;
+    int b = rl;
+    for (; b + 3 * LANES < nparts; b += 4 * LANES) {
+      a0 += p[(long)b * ld];
+      a1 += p[(long)(b + LANES) * ld];
+      a2 += p[(long)(b + 2 * LANES) * ld];
+      a3 += p[(long)(b + 3 * LANES) * ld];
+    }
+    for (; b < nparts; b += LANES) a0 += p[(long)b * ld];
+  }
+  red[rl][cl] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   for (int half = LANES / 2; half > 0; half >>= 1) {      // fixed pairing: lane r += lane r + half
     if (rl < half) red[rl][cl] += red[rl + half][cl];
