@@ -39,6 +39,7 @@ struct GemmArgs {
   float* part_val;  // argmax epilogue: [N][n_parts]
   int* part_idx;
   int n_parts;
+  float* part;      // split-K without atomics: split ks stores its tile into part[ks][M][N] (plain stores); null = atomics
 };
 
 template <bool KM>
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_kernel(GemmArgs g) {
           if (row >= g.M) continue;
           float v = acc[i][j][r] * g.alpha + bv;
           if (g.resid && ks == 0) v += g.resid[(long)row * g.ldr + col];
-          atomicAdd((float*)g.C + (long)row * g.ldc + col, v);
+          if (g.part) g.part[((long)ks * g.M + row) * g.N + col] = v;
+          else atomicAdd((float*)g.C + (long)row * g.ldc + col, v);
         }
       }
     return;
@@ -419,7 +421,7 @@ bool bad_layout(const void* p, long ld, int contiguous_extent, bool kmajor) {
 
 int ctclip_gemm2_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                         long lda, long ldb, long ldc, long ldr, int a_kmajor, int b_kmajor, int c_fp32, int split_k,
-                        int accumulate, float alpha, int act, hipStream_t st);
+                        int accumulate, float alpha, int act, float* part, hipStream_t st);
 int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                         long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                         hipStream_t st);
@@ -427,7 +429,7 @@ int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* b
                            long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                            int hm_n, int hm_heads, hipStream_t st);
 int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
-                        float alpha, hipStream_t st);
+                        float alpha, float* part, hipStream_t st);
 int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
                            long ldb, hipStream_t st);
 extern "C" int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, int block, long ldh, long ldg, void* stream);
@@ -440,12 +442,28 @@ extern "C" {
 int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const float* resid,
                      int M, int N, int K, long lda, long ldb, long ldc, long ldr,
                      int a_kmajor, int b_kmajor, int c_fp32, int split_k, int accumulate, float alpha, int act,
-                     void* stream) {
+                     float* splitk_ws, long splitk_ws_floats, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (bad_layout(A, lda, a_kmajor ? K : M, a_kmajor) || bad_layout(B, ldb, b_kmajor ? K : N, b_kmajor)) return (int)hipErrorInvalidValue;
   if (act != 0 && act != 1) return (int)hipErrorInvalidValue;          // 0 none, 1 erf-GELU: nothing else is part of the ABI
   if (split_k > 1 && !accumulate) return (int)hipErrorInvalidValue;
   if (accumulate && (!c_fp32 || act != 0)) return (int)hipErrorInvalidValue;
+  if ((long)M * N >= (1L << 31)) splitk_ws = nullptr;
+  // Split-K with a workspace: every split stores its [M, N] partial product with plain stores (4-5x the rate of float
+  // atomics, which run at ~1.3 TB/s chip-wide: MI355X_MICROARCH.md) and ctclip_reduce_partials adds the partials to C in split
+  // order -- C += A B is then bit-reproducible.  The split count is cut to what the workspace holds; one split (or no
+  // workspace) accumulates straight into C, where every element has a single writer per launch.
+  float* part = nullptr;
+  if (accumulate && split_k > 1 && splitk_ws && ldc == N) {
+    const long per = (long)M * N;
+    const long fit = splitk_ws_floats / per;
+    if (split_k > fit) split_k = (int)(fit < 1 ? 1 : fit);
+    if (split_k > 1) part = splitk_ws;
+  }
+  auto finish = [&](int e, int splits) -> int {                        // second stage of the workspace form
+    if (e || !part) return e;
+    return ctclip_reduce_partials(part, splits, (long)M * N, (int)((long)M * N), (float*)C, (hipStream_t)stream);
+  };
   {
     // Problems with K % 64 == 0 and enough 256x128 tiles to fill the chip go to the pipelined LDS-DMA kernel (gemm2.hip):
     // 969/957 vs 748/750 TFLOP/s at 4096^3/8192^3; at 32 pairs/GPU FF1 forward 622 vs 561, FF1 wgrad 675 vs 526, kv wgrad
@@ -462,18 +480,28 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
         (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
       return ctclip_gemm3_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, nullptr, 0,
                                  (hipStream_t)stream);
-    // weight gradients (m-major x n-major, split over the tokens, f32 atomics) with enough 256 x 256 x split workgroups go
-    // to gemm4.hip, the transposed-operand form of the same tile.  CTCLIP_GEMM_NO_V4=1 disables it.
+    // weight gradients (m-major x n-major, split over the tokens) with enough 256 x 256 x split workgroups go to gemm4.hip,
+    // the transposed-operand form of the same tile.  CTCLIP_GEMM_NO_V4=1 disables it.
     static const bool no_v4 = CTCLIP_KNOB("CTCLIP_GEMM_NO_V4") != nullptr;
     const long blocks4 = blocks3 * (split_k > 1 ? split_k : 1);
     if (!no_v4 && !force_v1 && !a_kmajor && !b_kmajor && accumulate && c_fp32 && !bias && !resid && (K % 32) == 0 &&
-        (blocks4 >= 128 || v2_all))
-      return ctclip_gemm4_launch(A, B, C, M, N, K, lda, ldb, ldc, split_k, alpha, (hipStream_t)stream);
+        (blocks4 >= 128 || v2_all)) {
+      const int nk = K / 32;
+      const int s_eff = split_k < 1 ? 1 : (split_k > nk ? nk : split_k);
+      const int kps = (nk + s_eff - 1) / s_eff;
+      return finish(ctclip_gemm4_launch(A, B, C, M, N, K, lda, ldb, ldc, split_k, alpha, part, (hipStream_t)stream),
+                    (nk + kps - 1) / kps);
+    }
     const long blocks2 = (long)((M + 255) / 256) * ((N + 127) / 128) * (split_k > 1 ? split_k : 1);
     const bool eligible = !force_v1 && (K % 64) == 0 && blocks2 >= 192;
-    if (eligible || (v2_all && !force_v1 && (K % 64) == 0 && blocks2 >= 8))
-      return ctclip_gemm2_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, a_kmajor, b_kmajor, c_fp32, split_k,
-                                 accumulate, alpha, act, (hipStream_t)stream);
+    if (eligible || (v2_all && !force_v1 && (K % 64) == 0 && blocks2 >= 8)) {
+      const int nk = K / 64;
+      const int s_eff = split_k < 1 ? 1 : (split_k > nk ? nk : split_k);
+      const int kps = (nk + s_eff - 1) / s_eff;
+      return finish(ctclip_gemm2_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, a_kmajor, b_kmajor, c_fp32, split_k,
+                                        accumulate, alpha, act, part, (hipStream_t)stream),
+                    (nk + kps - 1) / kps);
+    }
   }
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
@@ -485,7 +513,9 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
   g.ktiles_per_split = (nk + split_k - 1) / split_k;
   g.split_k = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
   g.c_fp32 = c_fp32; g.atomic_out = accumulate ? 1 : 0; g.act = act; g.alpha = alpha;
-  return launch<0>(g, a_kmajor, b_kmajor, (hipStream_t)stream);
+  if (g.split_k <= 1) part = nullptr;
+  g.part = part;
+  return finish(launch<0>(g, a_kmajor, b_kmajor, (hipStream_t)stream), g.split_k);
 }
 
 // C = A[M,K] B[N,K]^T written as bf16 in the HEAD-MAJOR layout of attention_hm.hip: [part][sequence][head][token][32]
@@ -543,7 +573,7 @@ int ctclip_gemm_bf16_geglu(const void* A, const void* Bw, void* H, void* G, int 
   if (!no_v3 && aligned && (K % 32) == 0 && (N % 256) == 0 && (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
     return ctclip_gemm3_launch(A, Bw, H, nullptr, nullptr, M, N, K, lda, ldb, ldh, 0, 0, 1.0f, 2, G, ldg, (hipStream_t)stream);
   // small problems: the plain product, then the gated activation over the same interleaved layout
-  if (int e = ctclip_gemm_bf16(A, Bw, H, nullptr, nullptr, M, N, K, lda, ldb, ldh, 0, 1, 1, 0, 1, 0, 1.0f, 0, stream)) return e;
+  if (int e = ctclip_gemm_bf16(A, Bw, H, nullptr, nullptr, M, N, K, lda, ldb, ldh, 0, 1, 1, 0, 1, 0, 1.0f, 0, nullptr, 0, stream)) return e;
   return ctclip_geglu_fwd(H, G, M, inner, 32, ldh, ldg, stream);
 }
 
@@ -560,7 +590,7 @@ int ctclip_gemm_bf16_geglu_bwd(const void* dY, const void* W2T, void* H_dH, void
                                (hipStream_t)stream);
   // small problems: dg into the scratch, then the blocked GEGLU backward in place over h
   if (!dG_scratch) return (int)hipErrorInvalidValue;
-  if (int e = ctclip_gemm_bf16(dY, W2T, dG_scratch, nullptr, nullptr, M, inner, K, lddy, ldw, lddg, 0, 1, 1, 0, 1, 0, 1.0f, 0, stream))
+  if (int e = ctclip_gemm_bf16(dY, W2T, dG_scratch, nullptr, nullptr, M, inner, K, lddy, ldw, lddg, 0, 1, 1, 0, 1, 0, 1.0f, 0, nullptr, 0, stream))
     return e;
   return ctclip_geglu_bwd(dG_scratch, H_dH, H_dH, M, inner, 32, lddg, ldh, stream);
 }

@@ -30,6 +30,7 @@ struct Args {
   long lda, ldb, ldc, ldr;
   int M, N, K, tiles_m, tiles_n, split_k, ktiles_per_split, c_fp32, atomic_out, act;
   float alpha;
+  float* part;       // split-K without atomics: split ks stores its tile into part[ks][M][N]; null = atomics
 };
 
 template <bool KM>
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(Args g) {
           if (row >= g.M) continue;
           float v = acc[i][j][r] * g.alpha + bv;
           if (g.resid && ks == 0) v += g.resid[(long)row * g.ldr + col];
-          atomicAdd((float*)g.C + (long)row * g.ldc + col, v);
+          if (g.part) g.part[((long)ks * g.M + row) * g.N + col] = v;
+          else atomicAdd((float*)g.C + (long)row * g.ldc + col, v);
         }
       }
     return;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(Args g) {
 // called by ctclip_gemm_bf16 (gemm.hip) when K % 64 == 0 and the problem is large enough
 int ctclip_gemm2_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                         long lda, long ldb, long ldc, long ldr, int a_kmajor, int b_kmajor, int c_fp32, int split_k,
-                        int accumulate, float alpha, int act, hipStream_t st) {
+                        int accumulate, float alpha, int act, float* part, hipStream_t st) {
   using namespace g2;
   Args g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
@@ -309,6 +311,7 @@ int ctclip_gemm2_launch(const void* A, const void* B, void* C, const float* bias
   g.ktiles_per_split = (nk + split_k - 1) / split_k;
   g.split_k = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
   g.c_fp32 = c_fp32; g.atomic_out = accumulate ? 1 : 0; g.act = act; g.alpha = alpha;
+  g.part = g.split_k > 1 ? part : nullptr;
   const int nblk = g.tiles_m * g.tiles_n * g.split_k;
   const size_t lds = (size_t)NS * STAGE;           // 144 KiB: needs the opt-in above 64 KiB
   dim3 grid(nblk), block(NT);

@@ -1,6 +1,6 @@
 // bf16 MFMA GEMM, 256 x 256 x 32 tile for the weight gradients of the CT-CLIP step:
 //   dW[M,N] += alpha * A[K,M]^T B[K,N]   (A = dy, B = x, both row-major over K = all tokens, i.e. m-major x n-major),
-// split over K with f32 atomics into a zeroed / running dW (torch.nn.Linear's backward, attention.py:55-70, 144-183).
+// split over K -- partial tiles into a workspace summed in split order (reproducible), or f32 atomics -- into a zeroed / running dW (torch.nn.Linear's backward, attention.py:55-70, 144-183).
 //
 // These products have a tiny output and a contraction of ~10^6, so they are pure main loop.  gemm2.hip ran them on its
 // 256 x 128 x 64 tile (85 FLOP per operand byte, two 48 KiB stages in flight).  Here the tile of gemm3.hip is used with
@@ -28,6 +28,7 @@ struct Args {
   long lda, ldb, ldc;
   int M, N, K, tiles_m, tiles_n, split_k, ktiles_per_split;
   float alpha;
+  float* part;       // split-K without atomics: split ks stores its tile into part[ks][M][N] (plain stores); null = atomics
 };
 
 // [32 k][256 cols] bf16 tile, 512-byte rows of 32 16-byte chunks.  A transposed read touches, per 16-lane group, four
@@ -266,7 +267,9 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
         for (int r = 0; r < 4; ++r) {
           const int row = row0 + wm * 128 + i * 16 + 4 * q4 + r;
           if (row >= g.M) continue;
-          atomicAdd(g.C + (long)row * g.ldc + col, acc16[MF16 ? i : 0][MF16 ? j : 0][r] * g.alpha);
+          const float v = acc16[MF16 ? i : 0][MF16 ? j : 0][r] * g.alpha;
+          if (g.part) g.part[((long)ks * g.M + row) * g.N + col] = v;
+          else atomicAdd(g.C + (long)row * g.ldc + col, v);
         }
       }
     return;
@@ -282,7 +285,9 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * 128 + i * 32 + acc_row(r, half);
         if (row >= g.M) continue;
-        atomicAdd(g.C + (long)row * g.ldc + col, acc[i][j][r] * g.alpha);
+        const float v = acc[i][j][r] * g.alpha;
+        if (g.part) g.part[((long)ks * g.M + row) * g.N + col] = v;
+        else atomicAdd(g.C + (long)row * g.ldc + col, v);
       }
     }
 }
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
 
 // called by ctclip_gemm_bf16 (gemm.hip): m-major x n-major, K % 32 == 0, f32 accumulate output
 int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
-                        float alpha, hipStream_t st) {
+                        float alpha, float* part, hipStream_t st) {
   using namespace g4;
   Args g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = (float*)C;
@@ -303,6 +308,7 @@ int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int
   g.ktiles_per_split = (nk + split_k - 1) / split_k;
   g.split_k = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
   g.alpha = alpha;
+  g.part = g.split_k > 1 ? part : nullptr;
   const size_t lds = (size_t)NS * STAGE;           // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
 // depend on which workgroup finished first, so two runs of the same step give the same bits (the reference asks for
 // torch.use_deterministic_algorithms(True) in its attribution code, src/utils/visualizations.py:29-39).
 // ------------------------------------------------------------------------------------------------
-template <int CPB>                                        // columns per workgroup: 16 (x 16 row lanes) or 1 (x 256)
+template <int CPB>                                        // columns per workgroup: 64 (x 4 row lanes), 16 (x 16) or 1 (x 256)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, long ld,
                                                               int width, float* __restrict__ out) {
   constexpr int LANES = 256 / CPB;
@@ -252,7 +252,9 @@ inline unsigned grid_for(long work, long cap = 2048) {
 
 int ctclip_reduce_partials(const float* partials, int nparts, long ld, int width, float* out, hipStream_t st) {
   if (nparts <= 0 || width <= 0) return 0;
-  if (width >= 16)
+  if (width >= 16384)                                      // split-K partial products: wide rows, 256-byte pieces per row lane
+    hipLaunchKernelGGL(reduce_partials_kernel<64>, dim3((width + 63) / 64), dim3(256), 0, st, partials, nparts, ld, width, out);
+  else if (width >= 16)
     hipLaunchKernelGGL(reduce_partials_kernel<16>, dim3((width + 15) / 16), dim3(256), 0, st, partials, nparts, ld, width, out);
   else
     hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3(width), dim3(256), 0, st, partials, nparts, ld, width, out);

@@ -54,10 +54,24 @@ def partials_scratch():
     return t
 
 
+SPLITK_WS_FLOATS = 36 << 20        # CTCLIP_SPLITK_WS_FLOATS
+_splitk = {}
+
+
+def splitk_scratch():
+    """The workspace behind `splitk_ws` of ctclip_gemm_bf16 (split-K partial products, summed in split order): one per
+    (device, stream), like partials_scratch()."""
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    t = _splitk.get(key)
+    if t is None:
+        t = _splitk[key] = torch.empty(SPLITK_WS_FLOATS, dtype=torch.float32, device="cuda")
+    return t
+
+
 class _Hip:
     """Attribute access gives a checked wrapper: tensors -> device pointers, None -> NULL, the trailing
-    `stream` argument defaults to torch's current stream (and a `partials` argument just before it to this stream's
-    scratch buffer), a non-zero return raises RuntimeError."""
+    `stream` argument defaults to torch's current stream (and a `partials` argument, or the `splitk_ws` /
+    `splitk_ws_floats` pair, just before it to this stream's scratch buffers), a non-zero return raises RuntimeError."""
 
     def __init__(self):
         self._dll = None
@@ -122,10 +136,13 @@ class _Hip:
         nargs = len(proto)
         has_stream = proto[-1][1] == "stream"
         has_partials = has_stream and nargs >= 2 and proto[-2][1] == "partials"
+        has_splitk = has_stream and nargs >= 3 and proto[-3][1] == "splitk_ws" and proto[-2][1] == "splitk_ws_floats"
 
         def call(*args):
             if has_partials and len(args) == nargs - 2:
                 args = (*args, partials_scratch())
+            if has_splitk and len(args) == nargs - 3:
+                args = (*args, splitk_scratch(), SPLITK_WS_FLOATS)
             if has_stream and len(args) == nargs - 1:
                 args = (*args, torch.cuda.current_stream().cuda_stream)
             if len(args) != nargs:

@@ -26,10 +26,11 @@
  *     are bit-identical from run to run: LayerNorm / head-norm / PEG parameter gradients, bias-gradient column sums, the
  *     squared gradient norm, d(temperature).  All forward kernels and all DATA gradients (dx, dq, dk, dv ...) are
  *     reproducible too.
- *     ORDER-DEPENDENT (f32 atomics, last-bit differences between runs): split-K products of ctclip_gemm_bf16 with
- *     accumulate=1 / split_k>1 (the weight gradients, the 294 912 -> 512 visual projection) and what is derived from one
- *     (ctclip_patch_affine_bwd is itself reproducible, but its input G is a split-K product), d(bias) of ctclip_attn_bwd
- *     (table and dense), ctclip_bert_embed_bwd (scatter-add by token id), embed_sum of ctclip_vq_ema_accum.
+ *     So are split-K products of ctclip_gemm_bf16 given a `splitk_ws` (the weight gradients, the 294 912 -> 512 visual
+ *     projection).
+ *     ORDER-DEPENDENT (f32 atomics, last-bit differences between runs): split-K products WITHOUT a workspace, d(bias) of
+ *     ctclip_attn_bwd / ctclip_attn_hm_bwd (table and dense), ctclip_bert_embed_bwd (scatter-add by token id), embed_sum of
+ *     ctclip_vq_ema_accum.
  */
 #ifndef CTCLIP_HIP_H
 #define CTCLIP_HIP_H
@@ -40,20 +41,26 @@ extern "C" {
 
 /* floats of scratch behind every `partials` argument (8 MiB) */
 #define CTCLIP_PARTIALS_FLOATS (1L << 21)
+/* floats of scratch that hold the split-K partial products of every GEMM of the CT-CLIP step (144 MiB) */
+#define CTCLIP_SPLITK_WS_FLOATS (36L << 20)
 
 /* ---- GEMM (MFMA) -------------------------------------------------------------------------------
  * C[M,N] = alpha * opA(A) opB(B) (+bias[N]) (+resid[M,N]) ; act: 0 none, 1 erf-GELU (anything else:
  * hipErrorInvalidValue).
  * a_kmajor=1: A is [M][K]; 0: A is [K][M].  b_kmajor=1: B is [N][K] (nn.Linear weight); 0: [K][N].
- * c_fp32: output f32 instead of bf16.  accumulate=1: C (f32) += result with atomics (caller
- * pre-initialises C; bias/resid added once); split_k>1 splits K over workgroups and needs accumulate.
+ * c_fp32: output f32 instead of bf16.  accumulate=1: C (f32) += result (caller pre-initialises C; bias/resid added
+ * once); split_k>1 splits K over workgroups and needs accumulate.  splitk_ws (optional scratch of splitk_ws_floats floats,
+ * private to the stream while the call runs; CTCLIP_SPLITK_WS_FLOATS holds every product of the path): each split stores
+ * its [M, N] partial product there with plain stores and the partials are added to C in split order -- reproducible, and
+ * faster than float atomics (~1.3 TB/s chip-wide); the split count is cut to what the scratch holds.  Without it (or when
+ * ldc != N) the splits add to C with f32 atomics.
  * Replaces every nn.Linear / einsum GEMM of the path: attention.py:47,50,118-119,124,142;
  * ctvit.py:50; ctclip.py:115-116,127; transformers BertSelfAttention/BertIntermediate/BertOutput
  * dense layers; and their autograd (dgrad: a_kmajor=1,b_kmajor=0; wgrad: 0,0). */
 int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, const float* resid,
                      int M, int N, int K, long lda, long ldb, long ldc, long ldr,
                      int a_kmajor, int b_kmajor, int c_fp32, int split_k, int accumulate, float alpha, int act,
-                     void* stream);
+                     float* splitk_ws, long splitk_ws_floats, void* stream);
 
 /* scores = A[M,K] B[N,K]^T without materialising them: per column n, the top-2 (value, row) of each 64-row
  * slab of M.  part_val/part_idx are [N][2*ceil(M/128)][2]; empty slots carry index 0x7fffffff.  VQ nearest-code

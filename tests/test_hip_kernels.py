@@ -895,6 +895,7 @@ def test_two_stage_reductions_are_bitwise_reproducible(hip):
     y = torch.empty(rows, dim, device=DEV)
     hip.layernorm_fwd(x, gm, None, None, y, mean, rstd, rows, dim, 1e-5)
     noise = rnd(1 << 20, seed=73)
+    out_ref = {}
 
     def run_all():
         out = {}
@@ -920,6 +921,17 @@ def test_two_stage_reductions_are_bitwise_reproducible(hip):
         hip.sumsq_accum(x.reshape(-1), x.numel(), ss)
         hip.dot_accum(x.reshape(-1), dy.reshape(-1), dt, x.numel())
         out["sumsq"], out["dot"] = ss, dt
+        # split-K weight gradient (m-major x n-major, K = tokens) with the workspace: partial tiles + ordered sum
+        tok, nf, kf = 8192, 256, 320
+        gy, gx = bf(rnd(tok, nf, seed=79)), bf(rnd(tok, kf, seed=80))
+        dwt = torch.zeros(nf, kf, device=DEV)
+        hip.gemm_bf16(gy, gx, dwt, None, None, nf, kf, tok, nf, kf, kf, 0, 0, 0, 1, 16, 1, 1.0, 0)
+        out["split-K wgrad"] = dwt
+        if "ref wgrad" not in out_ref:
+            out_ref["ref wgrad"] = gy.float().t() @ gx.float()
+            atom = torch.zeros(nf, kf, device=DEV)                         # the same product without a workspace: f32 atomics
+            hip.gemm_bf16(gy, gx, atom, None, None, nf, kf, tok, nf, kf, kf, 0, 0, 0, 1, 16, 1, 1.0, 0, None, 0)
+            out_ref["atomics wgrad"] = atom
         B, T, Hh, Ww, d = 3, 4, 24, 24, 32
         px, pdy = rnd(B, T, Hh, Ww, d, seed=77), rnd(B, T, Hh, Ww, d, seed=78)
         dw27, dbias = torch.zeros(27, d, device=DEV), torch.zeros(d, device=DEV)
@@ -933,6 +945,8 @@ def test_two_stage_reductions_are_bitwise_reproducible(hip):
     check("colsum value", first["colsum f32"], dy.sum(0), 1e-5)
     check("sumsq value", first["sumsq"], (x.double() ** 2).sum().float(), 1e-5)
     check("dot value", first["dot"], (x.double() * dy.double()).sum().float(), 1e-4)
+    check("split-K wgrad value (workspace)", first["split-K wgrad"], out_ref["ref wgrad"], 2e-3)
+    check("split-K wgrad value (atomics)", out_ref["atomics wgrad"], out_ref["ref wgrad"], 2e-3)
     for rep in range(3):
         again = run_all()
         for k, v in first.items():
