@@ -89,13 +89,15 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_dtype=BF1
 
 
 def _splits_for(m_out: int, n_out: int, k: int) -> int:
-    """split-K factor of a weight-gradient GEMM (small m_out x n_out, contraction over all tokens): at most two
-    workgroups of the 256x256x32 kernel (gemm4.hip, one resident per CU) for each of the 256 CUs, never a third partial
-    round, and at least 8 k-tiles per split."""
+    """split-K factor of a weight-gradient GEMM (small m_out x n_out, contraction over all tokens): ONE workgroup of the
+    256x256x32 kernel (gemm4.hip, one resident per CU) for each of the 256 CUs, and at least 8 k-tiles per split.  Every split
+    writes its partial tile to the split-K workspace and a second kernel sums them in order, so the partial volume grows
+    with the split count: measured at 64 pairs (tools/bench_gemm.py, WG = tiles x splits): out / q projections 256 us at 256
+    workgroups, 298 at 512, 344 at 768; kv 459 / 487 / 550; FF1, FF2 and the tubelet projection do not care."""
     if k % 32 == 0:
         nk = k // 32
         tiles = ((m_out + 255) // 256) * ((n_out + 255) // 256)
-        return max(1, min(nk // 8 if nk >= 8 else 1, max(1, 512 // tiles)))
+        return max(1, min(nk // 8 if nk >= 8 else 1, max(1, 256 // tiles)))
     nk = (k + 63) // 64
     tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
     return max(1, min(nk, (1024 + tiles - 1) // tiles))

@@ -39,10 +39,16 @@ for name, M, N, K, akm, bkm, cf, split, acc in shapes:
     if split == 0:
         from ctclip_hip.ops import _splits_for
         split = _splits_for(M, N, K)
+        if os.environ.get("WG"):                       # experiment: workgroups (tiles x splits) of a weight-gradient product
+            tiles = ((M + 255) // 256) * ((N + 255) // 256)
+            split = max(1, int(os.environ["WG"]) // tiles)
     ACT = int(os.environ.get("ACT", 0))
     LDC = N if not os.environ.get("LDC0") else 0
     def run():
-        hip.gemm_bf16(A, Bm, C, None, None, M, N, K, A.stride(0), Bm.stride(0), LDC, 0, akm, bkm, cf, split, acc, 1.0, ACT)
+        if os.environ.get("ATOMICS"):                  # split-K with f32 atomics instead of the workspace
+            hip.gemm_bf16(A, Bm, C, None, None, M, N, K, A.stride(0), Bm.stride(0), LDC, 0, akm, bkm, cf, split, acc, 1.0, ACT, None, 0)
+        else:
+            hip.gemm_bf16(A, Bm, C, None, None, M, N, K, A.stride(0), Bm.stride(0), LDC, 0, akm, bkm, cf, split, acc, 1.0, ACT)
     for _ in range(3): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 10
