@@ -263,17 +263,78 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const long* __restr
     ((float4*)out)[e] = make_float4(a.x + b.x + d.x, a.y + b.y + d.y, a.z + b.z + d.z, a.w + b.w + d.w);
   }
 }
-__global__ __launch_bounds__(256) void bert_embed_bwd_kernel(const long* __restrict__ ids, const long* __restrict__ tt,
-                                                             const float* __restrict__ dy, float* __restrict__ dword,
-                                                             float* __restrict__ dpos, float* __restrict__ dtype_,
-                                                             long rows, int L, int H) {
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < rows * H; e += (long)gridDim.x * 256) {
-    const long r = e / H;
-    const int c = (int)(e % H);
-    const float g = dy[e];
-    atomicAdd(dword + ids[r] * H + c, g);
-    atomicAdd(dpos + (r % L) * H + c, g);
-    atomicAdd(dtype_ + (tt ? tt[r] : 0) * H + c, g);
+// Backward of the three embedding tables, without atomics (every sum has one owner and a fixed order, so the gradients are
+// bit-reproducible; the f32-atomic scatter this replaces ran at the chip's ~1.3 TB/s atomic rate):
+//   d(pos)[p]   += sum over the sequences b, in order, of dy[b L + p]                      one thread per (p, 4 columns)
+//   d(type)[v]  += sum of dy[r] over the rows with token_type v                            chunk partials + ordered sum
+//   d(word)[id] += sum of dy[r] over the rows with ids[r] == id, in row order              one workgroup per row: the FIRST
+//       row of every id owns the sum -- it scans the id list for its later occurrences (list kept in LDS, in row order)
+__global__ __launch_bounds__(256) void bert_embed_bwd_pos_kernel(const float* __restrict__ dy, float* __restrict__ dpos,
+                                                                 long rows, int L, int H4) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)L * H4) return;
+  const int p = (int)(e / H4), c = (int)(e % H4);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long r = p; r < rows; r += L) {
+    const float4 g = ((const float4*)dy)[r * H4 + c];
+    acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+  }
+  float4* o = (float4*)dpos + e;
+  float4 v = *o;
+  v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
+  *o = v;
+}
+
+constexpr int EMB_NT = 4;          // token types handled per launch (BERT has 2)
+__global__ __launch_bounds__(256) void bert_embed_bwd_type_kernel(const long* __restrict__ tt, const float* __restrict__ dy,
+                                                                  float* __restrict__ partials, long rows, int H, int ntypes,
+                                                                  int rows_per_chunk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = (r0 + rows_per_chunk < rows) ? r0 + rows_per_chunk : rows;
+  if (c >= H) return;
+  float acc[EMB_NT];
+#pragma unroll
+  for (int v = 0; v < EMB_NT; ++v) acc[v] = 0.f;
+  for (long r = r0; r < r1; ++r) {
+    const int v = tt ? (int)tt[r] : 0;
+    const float g = dy[r * H + c];
+#pragma unroll
+    for (int u = 0; u < EMB_NT; ++u) acc[u] += (u == v) ? g : 0.f;
+  }
+  for (int v = 0; v < ntypes; ++v) partials[((long)blockIdx.y * ntypes + v) * H + c] = acc[v];
+}
+
+__global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const long* __restrict__ ids, const float* __restrict__ dy,
+                                                                  float* __restrict__ dword, int rows, int H) {
+  extern __shared__ int emb_list[];                         // rows of this id, ascending
+  __shared__ int found, wave_cnt[4], list_len;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long id = ids[r];
+  if (tid == 0) { found = 0; list_len = 0; }
+  __syncthreads();
+  int dup = 0;
+  for (int j = tid; j < r; j += 256) dup |= (ids[j] == id);
+  if (dup) found = 1;                                       // benign race: every writer stores 1
+  __syncthreads();
+  if (found) return;                                        // an earlier row owns this id
+  for (int base = r; base < rows; base += 256) {
+    const int j = base + tid;
+    const bool hit = j < rows && ids[j] == id;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = list_len;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (hit) emb_list[off + __popcll(m & ((1ull << lane) - 1ull))] = j;
+    __syncthreads();
+    if (tid == 0) list_len += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  const int n = list_len;
+  for (int c = tid; c < H; c += 256) {
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc += dy[(long)emb_list[i] * H + c];
+    dword[id * H + c] += acc;
   }
 }
 }  // namespace
@@ -288,10 +349,28 @@ int ctclip_bert_embed_fwd(const long* ids, const long* token_type, const float* 
   CTCLIP_CHECK_LAUNCH();
 }
 int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* dy, float* dword, float* dpos,
-                          float* dtype, long rows, int L, int hidden, void* stream) {
+                          float* dtype, long rows, int L, int hidden, int type_vocab, float* partials, void* stream) {
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(bert_embed_bwd_kernel, dim3(grid_for(rows * hidden)), dim3(256), 0, (hipStream_t)stream, ids,
-                     token_type, dy, dword, dpos, dtype, rows, L, hidden);
+  if ((hidden & 3) || L <= 0 || rows % L || type_vocab < 1 || type_vocab > EMB_NT || !partials || rows > (1L << 30))
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bert_embed_bwd_pos_kernel, dim3((unsigned)(((long)L * (hidden / 4) + 255) / 256)), dim3(256), 0, st, dy,
+                     dpos, rows, L, hidden / 4);
+  long maxchunks = kPartialsFloats / ((long)type_vocab * hidden);
+  if (maxchunks > 64) maxchunks = 64;
+  if (maxchunks < 1) return (int)hipErrorInvalidValue;
+  long rpc = (rows + maxchunks - 1) / maxchunks;
+  if (rpc < 32) rpc = 32;
+  const int nchunks = (int)((rows + rpc - 1) / rpc);
+  hipLaunchKernelGGL(bert_embed_bwd_type_kernel, dim3((hidden + 255) / 256, nchunks), dim3(256), 0, st, token_type, dy, partials,
+                     rows, hidden, type_vocab, (int)rpc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (int r = ctclip_reduce_partials(partials, nchunks, (long)type_vocab * hidden, type_vocab * hidden, dtype, st)) return r;
+  const size_t lds = (size_t)rows * sizeof(int);
+  if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
+  if (lds > 65536) hipFuncSetAttribute((const void*)bert_embed_bwd_word_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(bert_embed_bwd_word_kernel, dim3((unsigned)rows), dim3(256), lds, st, ids, dy, dword, (int)rows, hidden);
   CTCLIP_CHECK_LAUNCH();
 }
 }

@@ -408,6 +408,14 @@ LOG2E = 1.4426950408889634
 LN2 = 0.6931471805599453
 
 
+def deterministic() -> bool:
+    """True when bit-reproducible results are asked for -- torch.use_deterministic_algorithms(True), the switch the
+    reference's attribution code sets at import (src/utils/visualizations.py:29-39).  Almost everything on this path is
+    reproducible unconditionally (include/ctclip_hip.h, "reproducibility"); the flag only selects the ordered form of
+    the one sum whose fast form is order-dependent: the relative-position d(bias) of the spatial attention."""
+    return torch.are_deterministic_algorithms_enabled()
+
+
 def attn_head_major_ok(n, dh, dp, dim, want_probs):
     """Shapes the head-major spatial-attention kernels (csrc/attention_hm.hip) take: d_head 32, whole 32-token tiles, at most
     20 of them (the d(bias) tiles of a query block and the wave images fill the LDS), and nobody asking for the
@@ -515,17 +523,33 @@ class AttentionFn(Function):
             dtable = torch.zeros(heads, tsize, dtype=F32, device=dev)
             gh, gw = aux.get("grid", (0, 0))
             rel = None if gw else aux["relidx"]
+        # deterministic algorithms requested: the gradient passes run WITHOUT the bias gradient (its fast form adds the
+        # sequences' dS tiles under LDS locks, in arrival order) and ctclip_attn_dbias_ordered sums them in sequence order
+        ordered = deterministic() and (dbias_dense is not None or dtable is not None)
+        if ordered and dtable is not None and not gw:
+            raise NotImplementedError("deterministic d(bias) of an index table that is not a 2-D relative-position grid")
+        fast_dense, fast_table = (None, None) if ordered else (dbias_dense, dtable)
+        f_rel, f_ts, f_gh, f_gw = (None, 0, 0, 0) if ordered else (rel, tsize, gh, gw)
         if hm:
             # d(o) = dy Wout as a k-major x k-major product with the transposed weight shadow, written head-major
             do = torch.empty(nseq, heads, n, dp, dtype=BF16, device=dev)
             hip.gemm_bf16_headmajor(dyb, sh["woutT"], do, M, inner, dim, dyb.stride(0), sh["woutT"].stride(0), n, heads)
-            hip.attn_hm_bwd(qh, kh, kv[1], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, dbias_dense, rel, dtable,
-                            tsize, gh, gw, nseq, n, heads, inner, inner, inner, 2 * inner)
+            hip.attn_hm_bwd(qh, kh, kv[1], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, fast_dense, f_rel, fast_table,
+                            f_ts, f_gh, f_gw, nseq, n, heads, inner, inner, inner, 2 * inner)
         else:
             do = dgrad(dyb, sh["wout"], M, dim, inner, out_dtype=BF16, wT16=sh.get("woutT"))
             hip.attn_bwd(qh, kh, kv[:, inner:], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, None,
-                         dbias_dense, rel, dtable, tsize, gh, gw, nseq, n, heads, dp,
+                         fast_dense, f_rel, fast_table, f_ts, f_gh, f_gw, nseq, n, heads, dp,
                          inner, inner, 2 * inner, inner, inner, inner, inner, 2 * inner, LN2)
+        if ordered:
+            dense = dbias_dense if dbias_dense is not None else torch.zeros(heads, n, n, dtype=F32, device=dev)
+            if hm:
+                hip.attn_dbias_ordered(qh, kh, kv[1], do, lse, delta, bias_dense, dense, nseq, n, heads, 1, 0, 0, 0, 0, LN2)
+            else:
+                hip.attn_dbias_ordered(qh, kh, kv[:, inner:], do, lse, delta, bias_dense, dense, nseq, n, heads, 0,
+                                       inner, inner, 2 * inner, inner, LN2)
+            if dtable is not None:
+                hip.attn_dbias_table(dense, dtable, heads, gh, gw)
         k_raw, k_ld, k_hm = (kv[0], 0, n) if hm else (kv, 2 * inner, 0)
         p_gamma, p_wq, p_wkv, p_qs, p_ks, p_wout = ctx.params
         dq = torch.empty(M, inner, dtype=BF16, device=dev)
@@ -814,10 +838,21 @@ class VQFn(Function):
 
 def vq_ema_accum(x2, inv, idx, ncodes, d):
     """Per-code statistics of the library's cosine-sim codebook update: -> (bins [ncodes], esum [ncodes, d], flat), the
-    first two being views of the one flat buffer (so a data-parallel run reduces both with one collective)."""
+    first two being views of the one flat buffer (so a data-parallel run reduces both with one collective).
+
+    No atomics: the tokens are sorted by code (stable, so equal codes keep token order), the counts are the segment
+    lengths, and ctclip_vq_ema_accum_sorted sums each code's rows in that order -- bit-reproducible, and faster than the
+    ~450 M float atomics of the scatter-add form at the production shape."""
+    M = x2.shape[0]
     flat = torch.zeros(ncodes * (d + 1), dtype=F32, device=x2.device)
     bins, esum = flat[:ncodes], flat[ncodes:].view(ncodes, d)
-    hip.vq_ema_accum(x2, inv, idx.reshape(-1), bins, esum, x2.shape[0], d)
+    code_sorted, order = torch.sort(idx.reshape(-1), stable=True)
+    seg = torch.searchsorted(code_sorted, torch.arange(ncodes + 1, device=x2.device, dtype=code_sorted.dtype))
+    bins.copy_((seg[1:] - seg[:-1]).to(F32))
+    nchunks = (M + 255) // 256
+    edge = torch.empty(2 * nchunks * d, dtype=F32, device=x2.device)
+    edge_code = torch.empty(3 * nchunks, dtype=torch.long, device=x2.device)
+    hip.vq_ema_accum_sorted(x2, inv, order, code_sorted, esum, edge, edge_code, M, d)
     return bins, esum, flat
 
 

@@ -28,9 +28,10 @@
  *     reproducible too.
  *     So are split-K products of ctclip_gemm_bf16 given a `splitk_ws` (the weight gradients, the 294 912 -> 512 visual
  *     projection).
- *     ORDER-DEPENDENT (f32 atomics, last-bit differences between runs): split-K products WITHOUT a workspace, d(bias) of
- *     ctclip_attn_bwd / ctclip_attn_hm_bwd (table and dense), ctclip_bert_embed_bwd (scatter-add by token id), embed_sum of
- *     ctclip_vq_ema_accum.
+ *     ORDER-DEPENDENT (f32 atomics / LDS locks, last-bit differences between runs): split-K products WITHOUT a workspace,
+ *     d(bias) of ctclip_attn_bwd / ctclip_attn_hm_bwd (table and dense; ctclip_attn_dbias_ordered is the reproducible form,
+ *     taken by the host layer under torch.use_deterministic_algorithms(True)), embed_sum of ctclip_vq_ema_accum
+ *     (ctclip_vq_ema_accum_sorted is the reproducible form and the one the host layer uses).
  */
 #ifndef CTCLIP_HIP_H
 #define CTCLIP_HIP_H
@@ -155,6 +156,17 @@ int ctclip_attn_hm_bwd(const void* q, const void* k, const void* v, const void* 
  * (the K/V projection attention.py:119,142 has two parts; the out-projection's data gradient one). */
 int ctclip_gemm_bf16_headmajor(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, int n_tokens,
                                int heads, void* stream);
+/* ---- reproducible d(bias) (csrc/attention_det.hip): dbias[heads, n, n] += sum over the sequences of dS = P (dP - delta), every
+ * (head, 32 x 32 tile) summed by one workgroup in sequence order -- what ctclip_attn_bwd / _hm_bwd compute with LDS locks and
+ * float atomics, bit-identical from run to run, at about the cost of a dQ pass.  Used when deterministic algorithms are
+ * requested (the reference's attribution code does: src/utils/visualizations.py:29-39); the gradient passes are then called
+ * without a bias gradient.  layout_hm = 1: q / k / v / dO head-major [nseq][heads][n][32] (ld* ignored); 0: row-major.
+ * natural logit = scale * (q . k) + bias;  d_head 32 (narrower heads zero-padded), any n.  ctclip_attn_dbias_table gathers the dense gradient into
+ * the [heads][(2 gh - 1)(2 gw - 1)] relative-position table of a gh x gw grid (one owner per entry, += ). */
+int ctclip_attn_dbias_ordered(const void* q, const void* k, const void* v, const void* dO, const float* lse,
+                              const float* delta, const float* bias, float* dbias, int nseq, int n, int heads, int layout_hm,
+                              long ldq, long ldk, long ldv, long lddo, float scale, void* stream);
+int ctclip_attn_dbias_table(const float* dbias_dense, float* dbias_table, int heads, int grid_h, int grid_w, void* stream);
 /* probabilities [nseq,heads,n,n] f32, for callers that want Attention.forward's second output */
 int ctclip_attn_probs(const void* q, const void* k, const float* lse, const float* bias, const float* mask,
                       float* probs, int nseq, int n, int heads, int dhead, long ldq, long ldk, float scale,
@@ -229,6 +241,12 @@ int ctclip_vq_select(const float* part_val, const int* part_idx, int n_cand, con
                      const float* embed, long* idx_out, float* quant, long ntok, int dim, float margin, void* stream);
 int ctclip_vq_ema_accum(const float* x, const float* inv_norm, const long* idx, float* bins, float* embed_sum, long ntok,
                         int dim, void* stream);
+/* embed_sum of the same update WITHOUT atomics, from the tokens sorted by code (stable): order[p] = token, code_sorted[p] = its
+ * code (nondecreasing).  Chunks of 256 sorted rows are summed in order; a code reaching across chunk borders is finished by
+ * the chunk where it begins, in chunk order: bit-reproducible.  Scratch: edge [2 ceil(ntok/256)][dim] floats, edge_code
+ * [3 ceil(ntok/256)] int64.  dim <= 1024.  (The counts are the segment lengths: the caller adds them to bins.) */
+int ctclip_vq_ema_accum_sorted(const float* x, const float* inv_norm, const long* order, const long* code_sorted,
+                               float* embed_sum, float* edge, long* edge_code, long ntok, int dim, void* stream);
 int ctclip_vq_ema_update(float* embed, float* cluster, const float* bins, const float* embed_sum, int ncodes, int dim,
                          float decay, void* stream);
 
@@ -271,8 +289,10 @@ int ctclip_dropout_bwd(const float* g, float* d, void* d_bf16, long n, float p, 
 /* ---- BERT embeddings (transformers BertEmbeddings): word[ids] + pos[0..L) + type[token_type] ---- */
 int ctclip_bert_embed_fwd(const long* ids, const long* token_type, const float* word, const float* pos, const float* type,
                           float* out, long rows, int L, int hidden, void* stream);
+/* backward: no atomics -- d(pos) one owner per entry, d(type) chunk partials + ordered sum, d(word) summed by the first row of
+ * every id over its later occurrences in row order: bit-reproducible.  rows % L == 0, rows <= 38 400, type_vocab <= 4. */
 int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* dy, float* dword, float* dpos,
-                          float* dtype, long rows, int L, int hidden, void* stream);
+                          float* dtype, long rows, int L, int hidden, int type_vocab, float* partials, void* stream);
 
 /* ---- volume ingest (src/utils/preprocess.py:84-152, model_type "ctclip"): raw scan [H,W,D] (f32 or i16) -> HU rescale
  * -> permute to [D,H,W] -> trilinear resample to (rD,rH,rW) (align_corners=False) -> clamp/1000 -> centre crop / pad with

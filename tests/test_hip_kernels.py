@@ -969,3 +969,111 @@ def test_gelu_tail_saturates(hip):
     assert float((err - 4e-3 * ref.abs()).max()) <= 4e-4                 # bf16 output rounding + the approximation
     big = h.float() > 3.7
     assert torch.equal(m[big], h[big])                                   # Phi = 1 exactly: gelu(x) = x
+
+
+def test_bert_embedding_backward_without_atomics(hip):
+    """ctclip_bert_embed_bwd (transformers BertEmbeddings backward): d(word) / d(position) / d(token type) against
+    torch's index_add on the same inputs -- ids with many repeats (and one id used by every row of a sequence), on top of
+    non-zero gradients already in the buffers -- and bit-identical from run to run."""
+    B, L, H, V, NT = 6, 40, 96, 50, 2
+    rows = B * L
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, (rows,), generator=g)
+    ids[L:2 * L] = 7                                                    # one id, a whole sequence long
+    tt = torch.randint(0, NT, (rows,), generator=g)
+    ids, tt = ids.to(DEV), tt.to(DEV)
+    dy = rnd(rows, H, seed=120)
+    base = {k: rnd(*shape, seed=s_) for k, shape, s_ in (("w", (V, H), 121), ("p", (64, H), 122), ("t", (NT, H), 123))}
+    ref_w = base["w"].clone().index_add_(0, ids, dy)
+    ref_p = base["p"].clone()
+    ref_p[:L] += dy.reshape(B, L, H).sum(0)
+    ref_t = base["t"].clone().index_add_(0, tt, dy)
+    outs = []
+    for _ in range(3):
+        dw, dp, dt = base["w"].clone(), base["p"].clone(), base["t"].clone()
+        hip.bert_embed_bwd(ids, tt, dy, dw, dp, dt, rows, L, H, NT)
+        outs.append((dw, dp, dt))
+    check("d(word)", outs[0][0], ref_w, 1e-5)
+    check("d(position)", outs[0][1], ref_p, 1e-5)
+    check("d(token type)", outs[0][2], ref_t, 1e-5)
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+    dw, dp, dt = base["w"].clone(), base["p"].clone(), base["t"].clone()
+    hip.bert_embed_bwd(ids, None, dy, dw, dp, dt, rows, L, H, NT)        # no token types given: all rows are type 0
+    check("d(token type), tt = None", dt[0], base["t"][0] + dy.sum(0), 1e-5)
+    assert torch.equal(dt[1], base["t"][1])
+
+
+# ---------------------------------------------------------------------------------------------- ordered (reproducible) sums
+@pytest.mark.parametrize("nseq,n,H,hm", [(37, 64, 2, True), (21, 40, 3, False), (12, 576, 8, True)])
+def test_ordered_bias_gradient_is_reproducible_and_equals_the_fast_one(hip, nseq, n, H, hm):
+    """ctclip_attn_dbias_ordered (csrc/attention_det.hip): the sum over the sequences of dS, every tile by one owner in
+    sequence order -- equal to the dense d(bias) of the training kernels up to f32 summation order, bit-identical from run
+    to run, on head-major and row-major operands, with a ragged last tile (n = 40); ctclip_attn_dbias_table gathers it into
+    the 2-D relative-position table exactly like an index_add."""
+    D, LOG2E, LN2 = 32, 1.4426950408889634, 0.6931471805599453
+    ld = H * D
+    unit = lambda t: torch.nn.functional.normalize(t.reshape(nseq * n, H, D), dim=-1).reshape(nseq * n, ld)
+    q, k = bf(unit(rnd(nseq * n, ld, seed=130)) * 8.0 * LOG2E), bf(unit(rnd(nseq * n, ld, seed=131)))
+    v, do = bf(rnd(nseq * n, ld, seed=132)), bf(rnd(nseq * n, ld, seed=133))
+    bias = rnd(H, n, n, seed=134)
+    o = torch.empty(nseq * n, ld, device=DEV, dtype=torch.bfloat16)
+    lse, delta = torch.empty(nseq, H, n, device=DEV), torch.empty(nseq, H, n, device=DEV)
+    dq, dk, dv = (torch.empty_like(o) for _ in range(3))
+    fast = torch.zeros(H, n, n, device=DEV)
+    if hm:
+        qx, kx, vx, dox = (to_hm(t, nseq, n, H, D) for t in (q, k, v, do))
+        hip.attn_hm_fwd(qx, kx, vx, o, lse, bias, None, nseq, n, H, ld)
+        hip.attn_hm_bwd(qx, kx, vx, o, dox, lse, delta, dq, dk, dv, bias, fast, None, None, 0, 0, 0, nseq, n, H, ld, ld, ld, ld)
+    else:
+        qx, kx, vx, dox = q, k, v, do
+        hip.attn_fwd(q, k, v, o, lse, bias, None, nseq, n, H, D, ld, ld, ld, ld, LN2)
+        hip.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, bias, None, fast, None, None, 0, 0, 0, nseq, n, H, D,
+                     ld, ld, ld, ld, ld, ld, ld, ld, LN2)
+    runs = []
+    for _ in range(3):
+        dense = torch.zeros(H, n, n, device=DEV)
+        hip.attn_dbias_ordered(qx, kx, vx, dox, lse, delta, bias, dense, nseq, n, H, int(hm), ld, ld, ld, ld, LN2)
+        runs.append(dense)
+    # the head-major training kernels round the bias to fp16 on its way into the score MFMA (2.4e-4 of each entry); the ordered
+    # form and the row-major kernels add it in f32
+    check("ordered vs fast d(bias)", runs[0], fast, 3e-3 if hm else 2e-5)
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    gh = next(d for d in (24, 8, 5, 4, 3, 2, 1) if n % d == 0)
+    gw = n // gh
+    ii = torch.arange(n, device=DEV)
+    rel = (ii[:, None] // gw - ii[None] // gw + gh - 1) * (2 * gw - 1) + (ii[:, None] % gw - ii[None] % gw + gw - 1)
+    R = (2 * gh - 1) * (2 * gw - 1)
+    table = torch.ones(H, R, device=DEV)
+    hip.attn_dbias_table(runs[0], table, H, gh, gw)
+    check("table from dense", table - 1, torch.zeros(H, R, device=DEV).index_add_(1, rel.reshape(-1), runs[0].reshape(H, -1)), 1e-5)
+
+
+@pytest.mark.parametrize("ntok,ncodes,dim,skew", [(5000, 64, 96, False), (3000, 16, 512, True), (700, 300, 32, False)])
+def test_sorted_codebook_statistics(hip, ntok, ncodes, dim, skew):
+    """ops.vq_ema_accum (ctclip_vq_ema_accum_sorted): per-code counts and sums of the normalised tokens from the stable sort
+    by code -- codes inside one 256-row chunk, codes across several chunks (a code owning 2000 tokens), empty codes --
+    against index_add, and bit-identical from run to run and to the token-order sum of each code."""
+    from ctclip_hip import ops
+    g = torch.Generator().manual_seed(9)
+    idx = torch.randint(0, ncodes, (ntok,), generator=g)
+    if skew:
+        idx[100:2100] = 3
+    idx = idx.to(DEV)
+    x = rnd(ntok, dim, seed=140)
+    inv = 1.0 / x.norm(dim=-1)
+    outs = [ops.vq_ema_accum(x, inv, idx, ncodes, dim) for _ in range(3)]
+    bins, esum, flat = outs[0]
+    ref = torch.zeros(ncodes, dim, device=DEV).index_add_(0, idx, x * inv[:, None])
+    check("embed_sum", esum, ref, 1e-5)
+    assert torch.equal(bins, torch.bincount(idx, minlength=ncodes).float())
+    assert flat.data_ptr() == bins.data_ptr()
+    for b2, e2, _ in outs[1:]:
+        assert torch.equal(e2, esum) and torch.equal(b2, bins)
+    c = int(idx[0])                                                       # one code's sum, token by token in token order:
+    seq = torch.zeros(dim, device=DEV)                                    # within one 256-row chunk the kernel adds exactly so
+    xn = x * inv[:, None]
+    if int((idx == c).sum()) <= 8:
+        for r_ in xn[idx == c]:
+            seq = seq + r_
+        check("token-order sum of one code", esum[c], seq, 1e-6)

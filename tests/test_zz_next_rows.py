@@ -140,3 +140,46 @@ def test_integrated_gradients_vs_oracle():
     agree = float(((m > 0) == (map_o > 0)).mean())
     print(f"  IG top-decile mask agreement with the oracle map: {agree:.4f}")
     assert agree >= 0.93
+
+
+def test_deterministic_mode_makes_the_training_step_bitwise_reproducible(tmp_path):
+    """torch.use_deterministic_algorithms(True) -- what the reference's attribution code sets at import
+    (src/utils/visualizations.py:29-39) -- selects the ordered form of the one sum whose fast form is order-dependent (the
+    relative-position d(bias)); every other reduction of the step is reproducible unconditionally (two-stage partial sums,
+    split-K through a workspace, sorted codebook statistics, owner-summed embedding gradients).  Then: two runs of the same
+    two training steps end in bit-identical states, and a run resumed from a checkpoint taken after step 1 equals the
+    uninterrupted run bit for bit -- losses, weights, codebook, Adam moments."""
+    from utils.CTClipTrainer import CTClipTrainer
+    was = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True)
+    try:
+        def run(resume_after_first=False):
+            clip, data, _ = _config1()
+            trainer = CTClipTrainer(clip, batch_size=4, results_folder=str(tmp_path))
+            (txt0, vol0), (txt1, vol1) = data
+            losses = [trainer.train_step((vol0, txt0))]
+            if resume_after_first:
+                trainer.save_model("det.pt")
+                ckpt = trainer.results_folder / "det.pt"
+                trainer.grad_sync.close()
+                clip2, _, _ = _config1()
+                trainer = CTClipTrainer(clip2, batch_size=4, results_folder=None)
+                trainer.load_model(ckpt)
+            losses.append(trainer.train_step((vol1, txt1)))
+            state = {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}
+            moments = [None if a is None else (a["m"].clone(), a["v"].clone()) for a in trainer.optim._arenas]
+            trainer.grad_sync.close()
+            return losses, state, moments
+
+        la, sa, ma = run()
+        for label, (lb, sb, mb) in (("second run", run()), ("resumed run", run(resume_after_first=True))):
+            assert la == lb, (label, la, lb)
+            for k in sa:
+                assert torch.equal(sa[k], sb[k]), f"{label}: {k} differs"
+            for x, y in zip(ma, mb):
+                assert (x is None) == (y is None)
+                if x is not None:
+                    assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), f"{label}: Adam moments differ"
+        print(f"  two runs and a resumed run of two training steps: bit-identical (losses {la})")
+    finally:
+        torch.use_deterministic_algorithms(was)
