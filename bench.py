@@ -421,6 +421,11 @@ def cpu_config1(O, reps, log):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: libraries that print to file descriptor 1 (RCCL's version banner at the first
+    # collective, gloo's connection messages) are sent to stderr for the whole run and the line goes to the real stdout
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -620,7 +625,8 @@ def main():
             out["attribution"] = attribution_bench(model, vol, txt, dev)
         if not args.no_cpu_baseline and not args.lean and world == 1 and not args.small:
             out["cpu_baseline"] = cpu_baseline(model, depth, size, args.text_len, text_cfg["vocab_size"])
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
