@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
 // applied by the VALU: p = exp2(S + nlse), dS = p * (dP - delta).
 // K / V tiles are fetched as 16 whole 64-byte rows per wave-instruction (1 KiB contiguous in the head-major layout) into a
 // wave-private LDS image and read back as MFMA operands: rows for S / dP, transposed for dQ^T += K^T dS^T.
-template <bool HAS_BIAS, int QB, int NW, bool DBL, bool RK1>
+template <bool HAS_BIAS, int QB, int NW, bool DBL, bool RK1, bool ROWLD = true>
 __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
   static_assert(!DBL || QB == 1, "the d(bias) tiles of one query block fill the LDS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -286,10 +286,13 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
   char* after_bias = smem + (size_t)(HAS_BIAS ? QB * T : 0) * 2048;
   float4* dbias_l = (float4*)after_bias;                           // DBL: [T][4][64] float4 = registers 4 j .. 4 j + 3 of lane
   unsigned* lock_l = (unsigned*)(after_bias + (size_t)T * 4096);   // DBL: one word per key tile
-  constexpr int IMG_BUFS = DBL ? 1 : 2;                            // [K 2 KiB | V 2 KiB] per buffer
-  constexpr int IMG_WAVE = 4096 * IMG_BUFS;
+  // ROWLD: K and V tiles are fetched as 16 whole rows per instruction into LDS images and every fragment is read back from
+  // them; !ROWLD: both arrive as MFMA fragments straight from global memory and only K is written to an image, for the
+  // transposed read of the dQ product (6 KiB less LDS traffic per tile: the d(bias) form is LDS-bound)
+  constexpr int IMG_BUFS = (DBL && ROWLD) ? 1 : 2;                 // [K 2 KiB | V 2 KiB] per buffer; K alone: two fit
+  constexpr int IMG_WAVE = (ROWLD ? 4096 : 2048) * IMG_BUFS;
   char* kimg = after_bias + (DBL ? (size_t)T * 4096 + 128 : 0) + (size_t)w * IMG_WAVE;
-  char* vimg = kimg + 2048 * IMG_BUFS;
+  char* vimg = kimg + 2048 * IMG_BUFS;                             // ROWLD only
   if (DBL) {
     for (int id = tid; id < T * 256; id += NW * 64) dbias_l[id] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int id = tid; id < T; id += NW * 64) lock_l[id] = 0u;
@@ -303,10 +306,12 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
   for (int j = 0; j < 8; ++j) ones01[j] = (half == 0 && j < 2) ? (_Float16)1.f : (_Float16)0.f;
 
   const int crow = lane >> 2, ccol = lane & 3;
-  const uint32_t kvoff = (uint32_t)(crow * 32 + ccol * 8);
+  const uint32_t kvoff = ROWLD ? (uint32_t)(crow * 32 + ccol * 8) : (uint32_t)(r * 32 + 8 * half);
+  const uint32_t kvstep = ROWLD ? 512u : 16u;                      // second piece: sixteen rows further / the other k-half
   const uint32_t qoff = (uint32_t)((q0 + r) * 32 + 8 * half);
   const uint32_t ooff = (uint32_t)((q0 + r) * a.ldo + head * 32 + 8 * half);
-  const uint32_t ist0 = img_off<32>(crow, ccol), ist1 = ist0 + 1024;   // sixteen rows further: same swizzle
+  const uint32_t ist0 = ROWLD ? img_off<32>(crow, ccol) : img_off<32>(r, half);
+  const uint32_t ist1 = ROWLD ? ist0 + 1024 : img_off<32>(r, 2 + half);   // sixteen rows further: same swizzle
   const long hstride = (long)a.n * 32, oseq = (long)a.n * a.ldo;
   const int rot = DBL ? (w * T) / NW : 0;                          // this wave's first key tile
   auto phys = [&](int it) { const int t = it + rot; return t >= T ? t - T : t; };
@@ -318,9 +323,9 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
     bf16x8 kr[2][2], vr[2][2];
     auto request = [&](int slot, int t) {
       kr[slot][0] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * 1024));
-      kr[slot][1] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * 1024 + 512));
+      kr[slot][1] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * 1024 + kvstep));
       vr[slot][0] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * 1024));
-      vr[slot][1] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * 1024 + 512));
+      vr[slot][1] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * 1024 + kvstep));
     };
     request(0, phys(0));
     if (T > 1) request(1, phys(1));
@@ -368,10 +373,13 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
       if (IMG_BUFS == 1) asm volatile("" ::: "memory");             // single image: the previous tile's reads stay above
       *(bf16x8*)(ki + ist0) = kr[slot][0];
       *(bf16x8*)(ki + ist1) = kr[slot][1];
-      *(bf16x8*)(vi + ist0) = vr[slot][0];
-      *(bf16x8*)(vi + ist1) = vr[slot][1];
-      const bf16x8 k0 = row_frag<32>(ki, 0, 0, lane), k1 = row_frag<32>(ki, 0, 1, lane);
-      const bf16x8 v0 = row_frag<32>(vi, 0, 0, lane), v1 = row_frag<32>(vi, 0, 1, lane);
+      bf16x8 k0 = kr[slot][0], k1 = kr[slot][1], v0 = vr[slot][0], v1 = vr[slot][1];
+      if (ROWLD) {
+        *(bf16x8*)(vi + ist0) = vr[slot][0];
+        *(bf16x8*)(vi + ist1) = vr[slot][1];
+        k0 = row_frag<32>(ki, 0, 0, lane); k1 = row_frag<32>(ki, 0, 1, lane);
+        v0 = row_frag<32>(vi, 0, 0, lane); v1 = row_frag<32>(vi, 0, 1, lane);
+      }
       const bf16x8 kt0 = tr_frag<32>(ki, 0, 0, 0, lane), kt1 = tr_frag<32>(ki, 0, 1, 0, lane);
       f32x16 dsb;                                                  // DBL: the block's dS tile for the d(bias) update
 #pragma unroll
@@ -782,6 +790,11 @@ int ctclip_attn_hm_bwd(const void* q, const void* k, const void* v, const void* 
     const bool rk1 = false;
 #endif
     constexpr bool DBL_RK1 = false;
+#ifdef CTCLIP_TUNING_KNOBS
+    const bool rowld = CTCLIP_KNOB("CTCLIP_HM_DBL_ROWLD") != nullptr;
+#else
+    const bool rowld = false;
+#endif
     auto lds_for = [&](int T, int nw) { return (size_t)(hb ? T : 0) * 2048 + (size_t)T * 4096 + 128 + (size_t)nw * 4096; };
     const int T = n / 32;
     if (lds_for(T, 12) <= 160 * 1024) {
@@ -796,6 +809,10 @@ int ctclip_attn_hm_bwd(const void* q, const void* k, const void* v, const void* 
                : hm_launch(hm_bwd_dq_kernel<false, 1, NWF, true, true>, p, nb, NWF, lds_for(T, NWF), st);
       else
 #endif
+      if (!rowld)
+        e = hb ? hm_launch(hm_bwd_dq_kernel<true, 1, NWF, true, DBL_RK1, false>, p, nb, NWF, lds_for(T, NWF), st)
+               : hm_launch(hm_bwd_dq_kernel<false, 1, NWF, true, DBL_RK1, false>, p, nb, NWF, lds_for(T, NWF), st);
+      else
       e = hb ? hm_launch(hm_bwd_dq_kernel<true, 1, NWF, true, DBL_RK1>, p, nb, NWF, lds_for(T, NWF), st)
              : hm_launch(hm_bwd_dq_kernel<false, 1, NWF, true, DBL_RK1>, p, nb, NWF, lds_for(T, NWF), st);
     } else {

@@ -416,11 +416,12 @@ def deterministic() -> bool:
     return torch.are_deterministic_algorithms_enabled()
 
 
-def attn_head_major_ok(n, dh, dp, dim, want_probs):
+def attn_head_major_ok(n, dh, dp, dim, heads, want_probs):
     """Shapes the head-major spatial-attention kernels (csrc/attention_hm.hip) take: d_head 32, whole 32-token tiles, at most
-    20 of them (the d(bias) tiles of a query block and the wave images fill the LDS), and nobody asking for the
-    probabilities."""
-    return dh == dp == 32 and n % 32 == 0 and 1 <= n // 32 <= 20 and dim % 32 == 0 and not want_probs
+    20 of them (the d(bias) tiles of a query block and the wave images fill the LDS), an even number of heads (the GEMM
+    epilogue that writes the layout works on 64-column slabs), and nobody asking for the probabilities."""
+    return (dh == dp == 32 and n % 32 == 0 and 1 <= n // 32 <= 20 and dim % 32 == 0 and heads % 2 == 0
+            and not want_probs)
 
 
 class AttentionFn(Function):
@@ -441,7 +442,7 @@ class AttentionFn(Function):
         M = nseq * n
         inner = heads * dp
         dev = x.device
-        hm = attn_head_major_ok(n, dh, dp, dim, want_probs)
+        hm = attn_head_major_ok(n, dh, dp, dim, heads, want_probs)
         qmult = float(scale) * LOG2E
         x2 = _c(x).reshape(M, dim)
         n1, _, mean, rstd = layernorm(x2, gamma.detach(), None, 1e-5)
