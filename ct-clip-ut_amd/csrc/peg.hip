@@ -184,6 +184,14 @@ __global__ __launch_bounds__(256) void peg_bwd_weight_kernel(const float* __rest
 // one write of y (+ y16) -- peg_sweep_kernel above pulls every element 3.75 times through L2 and re-reads x for the
 // residual.  One thread = 4 channels x PL_P consecutive w positions, three rotating accumulator sets as above.
 constexpr int PL_P = 6;            // outputs per thread along w (24 = 4 strips)
+// LDS plane images: rows of `pitch` 64-byte position blocks (16 channels).  A position block's banks are (column mod 4), and the
+// four blocks one LDS pass serves (16 lanes x 16 bytes, or 32 lanes x 8 bytes) belong to the four strips of one row: with the
+// strips side by side (PL_P = 6 columns apart) they sat on banks 0, 2, 0, 2 -- every access took two passes.  So the image
+// leaves one unused column between strips: padded column c (0 = left border, c = w + 1) lives at  c + strip(c) + 1  (the left
+// border at 0), a strip starts every PL_P + 1 = 7 columns (banks 0, 3, 2, 1), and a thread's PL_P + 2 taps sit at the
+// compile-time offsets plane_tap(i) from ITS strip's first column.
+__host__ __device__ inline int plane_pitch(int strips) { return strips * (PL_P + 1) + 3; }
+__host__ __device__ constexpr int plane_tap(int i) { return i == 0 ? 0 : (i <= PL_P ? i + 1 : PL_P + 3); }
 constexpr int PL_CG = 4;            // float4 channel groups per workgroup (16 channels)
 constexpr int PL_MAXT = 512;        // 8 waves -> 2 per SIMD -> 256 registers per thread
 
@@ -200,9 +208,9 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
   const int slice = blk % nslices;
   const long b = blk / nslices;
   const int cg = tid & (PL_CG - 1), sid = tid >> 2;
-  const int h_ = sid / strips, w0 = (sid % strips) * PL_P;
+  const int h_ = sid / strips, strip = sid % strips, w0 = strip * PL_P;
   const bool active = h_ < g.H;
-  const int pitch = strips * PL_P + 2;                       // padded row length (positions)
+  const int pitch = plane_pitch(strips);                     // row length of the image (position blocks)
   const int plane_f4 = (g.H + 2) * pitch * PL_CG;
   f32x4* wl = pl_smem;                                      // [27][PL_CG]
   f32x4* plane = pl_smem + 27 * PL_CG;                      // [2][(H+2)][pitch][PL_CG]
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
   };
   auto stage_plane = [&](int buf) {
     if (!active) return;
-    f32x4* dst = plane + buf * plane_f4 + ((h_ + 1) * pitch + w0 + 1) * PL_CG + cg;
+    f32x4* dst = plane + buf * plane_f4 + ((h_ + 1) * pitch + w0 + strip + 2) * PL_CG + cg;
 #pragma unroll
     for (int i = 0; i < PL_P; ++i) dst[i * PL_CG] = nx[i];
   };
@@ -266,10 +274,10 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int hp = FWD ? h_ + kh : h_ + 2 - kh;           // padded row of input row h_ + kh - 1 (FWD) / h_ - kh + 1
-      const f32x4* prow = pb + (hp * pitch + w0) * PL_CG + cg;
+      const f32x4* prow = pb + (hp * pitch + w0 + strip) * PL_CG + cg;
       f32x4 xs[PL_P + 2];
 #pragma unroll
-      for (int i = 0; i < PL_P + 2; ++i) xs[i] = prow[i * PL_CG];
+      for (int i = 0; i < PL_P + 2; ++i) xs[i] = prow[plane_tap(i) * PL_CG];
       if (residual && kh == 1) {                             // the residual term of output time tp is this plane's centre
 #pragma unroll
         for (int i = 0; i < PL_P; ++i) {
@@ -315,7 +323,7 @@ inline int plane_threads(int H, int W, int d, int* strips, size_t* lds) {
   const int st = (W + PL_P - 1) / PL_P;
   const int items = H * st * PL_CG;
   const int threads = (items + 63) / 64 * 64;
-  const size_t bytes = ((size_t)27 * PL_CG + (size_t)2 * (H + 2) * (st * PL_P + 2) * PL_CG) * sizeof(float4);
+  const size_t bytes = ((size_t)27 * PL_CG + (size_t)2 * (H + 2) * plane_pitch(st) * PL_CG) * sizeof(float4);
   if (threads > PL_MAXT || bytes > 160 * 1024) return 0;
   *strips = st;
   *lds = bytes;
@@ -329,24 +337,26 @@ inline int plane_threads(int H, int W, int d, int* strips, size_t* lds) {
 // issues 112 atomics per THREAD.
 //   dw27[kt,kh,kw][c] += sum dy[t,h,w][c] * x[t+kt-2, h+kh-1, w+kw-1][c];  dbias[c] += sum dy
 constexpr int WG_MAXT = 768;        // 12 waves -> 3 per SIMD -> 168 registers per thread
-constexpr int WG_C2 = 2 * PL_CG;    // float2 channel pairs per 16-channel slice
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-__global__ __launch_bounds__(WG_MAXT) void peg_wgrad_plane_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// WG_C2 = float2 channel pairs per slice: 8 (16-channel slices, 768 threads, one workgroup per CU).  Measured with 4 (8-channel
+// slices, 384 threads, half the LDS, two workgroups per CU): 2677 vs 1824 us -- 32-byte pieces of every line per workgroup
+template <int WG_C2>
+__global__ __launch_bounds__(WG_MAXT * WG_C2 / 8, 3) void peg_wgrad_plane_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                  float* __restrict__ partials, Grid5 g,
                                                                  int strips, int bchunk) {
   // one thread = 2 channels x PL_P consecutive w positions (float2 keeps the 28 accumulators at 56 registers)
   extern __shared__ __attribute__((aligned(16))) f32x2 wg_smem[];
   const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6;
-  const int nslices = g.d4 / PL_CG;
   const int d2 = g.d4 * 2;
+  const int nslices = d2 / WG_C2;
   const int blk = xcd_remap(blockIdx.x, gridDim.x);
   const int slice = blk % nslices;
   const long b0 = (long)(blk / nslices) * bchunk, b1 = (b0 + bchunk < g.B) ? b0 + bchunk : g.B;
-  const int c2 = tid & (WG_C2 - 1), sid = tid >> 3;
-  const int h_ = sid / strips, w0 = (sid % strips) * PL_P;
+  const int c2 = tid & (WG_C2 - 1), sid = tid / WG_C2;
+  const int h_ = sid / strips, strip = sid % strips, w0 = strip * PL_P;
   const bool active = h_ < g.H;
-  const int pitch = strips * PL_P + 2;
+  const int pitch = plane_pitch(strips);
   const int plane_f2 = (g.H + 2) * pitch * WG_C2;
   f32x2* ring = wg_smem;                                     // [3][(H+2)][pitch][WG_C2]
   const f32x2 zero = {0.f, 0.f};
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(WG_MAXT) void peg_wgrad_plane_kernel(const float* _
   f32x2 acc[28];
 #pragma unroll
   for (int i = 0; i < 28; ++i) acc[i] = zero;
-  const int own = ((h_ + 1) * pitch + w0 + 1) * WG_C2 + c2;  // this thread's first interior position inside a plane
+  const int own = ((h_ + 1) * pitch + w0 + strip + 2) * WG_C2 + c2;  // this thread's first interior position inside a plane
 
   f32x2 nx[PL_P], dcur[PL_P], dnext[PL_P];
   // x and dy share the layout: uniform plane base + one 32-bit per-thread offset (the positions follow at stride d2)
@@ -403,10 +413,10 @@ __global__ __launch_bounds__(WG_MAXT) void peg_wgrad_plane_kernel(const float* _
         const f32x2* pb = ring + ((t + kt + 1) % 3) * plane_f2;      // plane t + kt - 2
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-          const f32x2* prow = pb + ((h_ + kh) * pitch + w0) * WG_C2 + c2;
+          const f32x2* prow = pb + ((h_ + kh) * pitch + w0 + strip) * WG_C2 + c2;
           f32x2 xs[PL_P + 2];
 #pragma unroll
-          for (int i = 0; i < PL_P + 2; ++i) xs[i] = prow[i * WG_C2];
+          for (int i = 0; i < PL_P + 2; ++i) xs[i] = prow[plane_tap(i) * WG_C2];
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             f32x2 a = acc[(kt * 3 + kh) * 3 + kw];
@@ -427,11 +437,11 @@ __global__ __launch_bounds__(WG_MAXT) void peg_wgrad_plane_kernel(const float* _
     }
   }
 
-  // reduce the 28 partial sums over the threads that share a channel pair: lanes l ^ {8,16,32}, then the waves
+  // reduce the 28 partial sums over the threads that share a channel pair: lanes l ^ {WG_C2 .. 32}, then the waves
 #pragma unroll
   for (int i = 0; i < 28; ++i) {
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
+    for (int o = WG_C2; o < 64; o <<= 1) {
       f32x2 v = acc[i];
       v[0] = __shfl_xor(v[0], o, 64); v[1] = __shfl_xor(v[1], o, 64);
       acc[i] += v;
@@ -455,15 +465,15 @@ __global__ __launch_bounds__(WG_MAXT) void peg_wgrad_plane_kernel(const float* _
   }
 }
 
-inline int wgrad_plane_threads(int H, int W, int d, int* strips, size_t* lds) {
+inline int wgrad_plane_threads(int H, int W, int d, int WG_C2, int* strips, size_t* lds) {
   if (CTCLIP_KNOB("CTCLIP_PEG_SWEEP")) return 0;
   if ((d / 4) % PL_CG) return 0;
   const int st = (W + PL_P - 1) / PL_P;
   const int threads = (H * st * WG_C2 + 63) / 64 * 64;
-  size_t bytes = (size_t)3 * (H + 2) * (st * PL_P + 2) * WG_C2 * sizeof(float2);
+  size_t bytes = (size_t)3 * (H + 2) * plane_pitch(st) * WG_C2 * sizeof(float2);
   const size_t red = (size_t)(threads / 64) * WG_C2 * 28 * sizeof(float2);
   if (bytes < red) bytes = red;
-  if (threads > WG_MAXT || bytes > 160 * 1024) return 0;
+  if (threads > WG_MAXT * WG_C2 / 8 || bytes > (size_t)160 * 1024 * WG_C2 / 8) return 0;
   *strips = st;
   *lds = bytes;
   return threads;
@@ -545,24 +555,37 @@ int ctclip_peg_bwd_weight(const float* dy, const float* x, float* dw27, float* d
   {
     int strips = 0;
     size_t plds = 0;
-    const int threads = wgrad_plane_threads(H, W, d, &strips, &plds);
+    constexpr int c2 = 8;
+    const int threads = wgrad_plane_threads(H, W, d, c2, &strips, &plds);
     if (threads > 0) {
-      // ~2 rounds of one-per-CU workgroups; more batch items per workgroup = fewer partial rows
       static const int ncu = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
         return v;
       }();
-      const int nslices = g.d4 / PL_CG;
-      long nchunks = (2L * ncu) / nslices;
-      if (nchunks > kPartialsFloats / rowf) nchunks = kPartialsFloats / rowf;
-      if (nchunks < 1) nchunks = 1;
-      if (nchunks > B) nchunks = B;
-      const int bchunk = (int)((B + nchunks - 1) / nchunks);
-      nchunks = (B + bchunk - 1) / bchunk;
-      if (plds > 65536) hipFuncSetAttribute((const void*)peg_wgrad_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
-      hipLaunchKernelGGL(peg_wgrad_plane_kernel, dim3((unsigned)(nchunks * nslices)), dim3(threads), plds, st,
-                         dy, x, partials, g, strips, bchunk);
+      const int nslices = 2 * g.d4 / c2;
+      // batch items per workgroup: the workgroups run in rounds of one (two) per CU, and a round lasts as long as its longest
+      // chunk -- take the chunking with the fewest item-times (rounds x items per chunk) among one to four rounds, two rounds
+      // on a tie (the second round's workgroups start while the first round's stragglers finish).  88 items x 32 slices: 8
+      // chunks of 11 = exactly one round, 11 item-times, where two rounds of 6-item chunks take 12 (measured 1620 vs 1800 us);
+      // 64 items: two rounds of 4 (1150 us; one round of 8: 1185).
+      const long slots = (long)ncu * (8 / c2);
+      const long cap = kPartialsFloats / rowf;
+      long bchunk = B, best = -1;
+      for (int r : {2, 1, 3, 4}) {
+        long nc = (r * slots) / nslices;
+        if (nc > cap) nc = cap;
+        if (nc < 1) nc = 1;
+        if (nc > B) nc = B;
+        const long bc = (B + nc - 1) / nc;
+        nc = (B + bc - 1) / bc;
+        const long cost = ((nc * nslices + slots - 1) / slots) * bc;
+        if (best < 0 || cost < best) { best = cost; bchunk = bc; }
+      }
+      const long nchunks = (B + bchunk - 1) / bchunk;
+      if (plds > 65536) hipFuncSetAttribute((const void*)peg_wgrad_plane_kernel<c2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+      hipLaunchKernelGGL(peg_wgrad_plane_kernel<c2>, dim3((unsigned)(nchunks * nslices)), dim3(threads), plds, st,
+                         dy, x, partials, g, strips, (int)bchunk);
       return finish((int)nchunks);
     }
   }

@@ -165,6 +165,43 @@ def test_attention_golden():
     check("attn probs (no bias)", p2, g["attn.probs_nobias"], 3e-2)
 
 
+@pytest.mark.parametrize("heads,n", [(3, 64), (4, 64), (4, 80), (2, 704)])
+def test_attention_module_layout_choice_vs_oracle(heads, n):
+    """d_head 32 with an odd head count, a ragged last tile, or more tiles than the head-major kernels hold must fall back to
+    the row-major attention kernels; (4, 64) takes the head-major ones.  Same answers either way: output 3e-2 of peak,
+    gradients 6e-2 of peak against the f32 oracle (reference src/utils/attention.py:126-182)."""
+    from ctclip_hip import ops
+    from oracle import ctclip_oracle as O
+    from utils.attention import Attention
+    dim = 64
+    torch.manual_seed(heads * 1000 + n)
+    at = Attention(dim=dim, dim_head=32, heads=heads)
+    with torch.no_grad():
+        at.q_scale.copy_(1.0 + 0.2 * torch.randn(32))
+        at.k_scale.copy_(1.0 + 0.2 * torch.randn(32))
+        at.norm.gamma.copy_(1.0 + 0.2 * torch.randn(dim))
+    st = {k: v.detach().clone().requires_grad_(v.is_floating_point() and v.numel() > 0 and not k.endswith("beta"))
+          for k, v in at.state_dict().items()}
+    x = torch.randn(5, n, dim)
+    bias = 0.5 * torch.randn(heads, n, n)
+    r = torch.randn(5, n, dim)
+    xo, bo = x.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yo, _ = O.attention(xo, st, "", heads, attn_bias=bo)
+    (yo * r).sum().backward()
+    assert ops.attn_head_major_ok(n, 32, 32, dim, heads, False) == ((heads, n) == (4, 64))
+    at = at.to(DEV)
+    xh, bh = x.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    out = at(xh, attn_bias=bh)
+    yh = out[0] if isinstance(out, tuple) else out
+    check("attention y", yh, yo, 3e-2)
+    (yh * r.to(DEV)).sum().backward()
+    check("attention dx", xh.grad, xo.grad, 6e-2)
+    check("attention dbias", bh.grad, bo.grad, 6e-2)
+    named = dict(at.named_parameters())
+    for k in ("q_scale", "k_scale", "norm.gamma", "to_q.weight", "to_kv.weight", "to_out.weight"):
+        check("attention d" + k, named[k].grad, st[k].grad, 6e-2)
+
+
 def test_position_bias_golden():
     from utils.attention import ContinuousPositionBias
     g = load_golden("blocks")
