@@ -431,7 +431,7 @@ int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* b
 int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
                         float alpha, float* part, hipStream_t st);
 int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
-                           long ldb, hipStream_t st);
+                           long ldb, int cgroups, hipStream_t st);
 extern "C" int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, int block, long ldh, long ldg, void* stream);
 extern "C" int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, int block, long lddg, long ldh,
                                 void* stream);
@@ -538,13 +538,24 @@ int ctclip_vq_topk(const void* A, const void* B, float* part_val, int* part_idx,
   // whole 256-code tiles: the 256 x 256 LDS-DMA form in gemm3.hip (CTCLIP_VQ_NO_V3=1 keeps the kernel below)
   static const bool no_v3 = CTCLIP_KNOB("CTCLIP_VQ_NO_V3") != nullptr;
   if (!no_v3 && (M % 256) == 0 && (K % 32) == 0)
-    return ctclip_vq_topk3_launch(A, B, part_val, part_idx, M, N, K, lda, ldb, (hipStream_t)stream);
+    return ctclip_vq_topk3_launch(A, B, part_val, part_idx, M, N, K, lda, ldb, 1, (hipStream_t)stream);
   GemmArgs g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.part_val = part_val; g.part_idx = part_idx; g.n_parts = 4 * VQ_TOP;
   hipLaunchKernelGGL(gemm_vq_topk_kernel, dim3(g.tiles_n), dim3(NTHREADS), 4 * TILE_BYTES, (hipStream_t)stream, g);
   return (int)hipGetLastError();
+}
+
+// The same search with the codebook split into `code_groups` groups of whole 256-code tiles (gemm3.hip, "CODE GROUPS"): 16
+// candidates per token AND group, part_val / part_idx are [N][16 * code_groups].  code_groups must divide 32 and M / 256;
+// M % 256 == 0, K % 32 == 0.  code_groups = 1 is ctclip_vq_topk.
+int ctclip_vq_topk_grouped(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
+                           long ldb, int code_groups, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (code_groups == 1) return ctclip_vq_topk(A, B, part_val, part_idx, M, N, K, lda, ldb, stream);
+  if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true) || (M % 256) || (K % 32)) return (int)hipErrorInvalidValue;
+  return ctclip_vq_topk3_launch(A, B, part_val, part_idx, M, N, K, lda, ldb, code_groups, (hipStream_t)stream);
 }
 
 // (older per-tile variant, kept for the kernel tests) top-2 over the rows of each 64-row slab:

@@ -585,12 +585,30 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
 // registers cover; a token ends with 4 lane groups (wm, lane half) x 4 = 16 candidates from disjoint parts of the
 // codebook, which ctclip_vq_select re-ranks exactly in f32.  Against the 128 x 128 register-staged kernel of gemm.hip
 // this halves the operand bytes pulled through L2 per flop (the codebook is re-streamed once per 256 tokens, not 128).
-// Preconditions (gemm.hip): M % 256 == 0, K % 32 == 0.
+//
+// CODE GROUPS (cgroups > 1; ctclip_vq_topk_grouped): an experiment on WHERE this kernel's fabric traffic comes from (27 GB per
+// launch at 64 pairs against 1.4 GB of operands).  A workgroup re-reads its own 256 KiB token tile for every code tile; with
+// one workgroup per (token tile, whole codebook) the 32 workgroups resident on an XCD keep 8 MiB of token tiles + the 8 MiB
+// codebook moving through a 4 MiB L2.  With code groups the 32 workgroups an XCD holds at a time are `ttiles` token tiles x
+// `cgroups` code groups (8 x 4): 2 MiB of token tiles, each shared by four workgroups, and every code tile shared by the
+// eight token tiles that sweep it side by side -- 10 MiB per XCD round if the L2 kept them.  MEASURED
+// (profiles/r03_vq_code_groups.txt; tools/probe_xcd.py confirms XCD = block % 8 and in-order rounds of 32): FETCH_SIZE per
+// launch 33.4 GB with one group, 23.4 / 23.5 / 29.2 GB with 2 / 4 / 8 -- the workgroups of an XCD find only part of each
+// other's lines in its L2 however the work is cut (54 MiB per XCD round with 4 groups) -- and the sweep gets slower (8.5 ->
+// 9.0 ms at 64 pairs with 4 groups, 9.6 with 8: four / eight times the workgroups, each paying the ring fill and the candidate
+// write).  The traffic is served by the 256 MiB Infinity Cache and is not what bounds the kernel (matrix pipe + LDS issue,
+// section 4.3 of DESIGN.md).  One group is the default; the grouped form stays as a tested entry point.
+// A token ends with 16 candidates PER GROUP, part_val / part_idx are [N][16 * cgroups]; ctclip_vq_select takes any candidate
+// count, and the union contains the top-4 of every (wave row, lane half) part of the whole codebook, i.e. everything the
+// one-group form keeps.
+// Block b runs on XCD b % 8; its XCD-local index b / 8 is (group of 8 x ttiles token tiles, slot, code group).
+// Preconditions (gemm.hip): M % 256 == 0, K % 32 == 0, (M / 256) % cgroups == 0.
 // ------------------------------------------------------------------------------------------------------------------
 struct VqArgs {
   const bf16_t* A; const bf16_t* B;
   long lda, ldb;
-  int M, N, K, tiles_m;
+  int M, N, K, tiles_m;                  // tiles_m: code tiles per workgroup (= per code group)
+  int cgroups, ttiles, ntok_tiles;
   float* part_val; int* part_idx;
 };
 constexpr int VQ_TOP = 4;                       // the insertion below is written out for exactly four places
@@ -602,7 +620,18 @@ __global__ __launch_bounds__(512, 2) void vq_topk3_kernel(VqArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  const int col0 = xcd_remap(blockIdx.x, gridDim.x) * BN;      // token tile
+  int tok_tile, cgrp = 0;
+  if (g.cgroups > 1) {
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3, per = g.ttiles * g.cgroups;
+    const int grp = loc / per, within = loc - grp * per;
+    cgrp = within % g.cgroups;
+    tok_tile = (grp * 8 + xcd) * g.ttiles + within / g.cgroups;
+    if (tok_tile >= g.ntok_tiles) return;                      // whole workgroup, before any barrier
+  } else {
+    tok_tile = xcd_remap(blockIdx.x, gridDim.x);
+  }
+  const int col0 = tok_tile * BN;                              // token tile
+  const int code0 = cgrp * g.tiles_m * BM;                     // first code of this workgroup's group
   const int nk = g.K / BK;
   const int steps = g.tiles_m * nk;                            // flattened (code tile, K-step) sequence
   const int half = lane >> 5, lc = lane & 31;
@@ -613,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void vq_topk3_kernel(VqArgs g) {
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
     const int q = wave * PPW + j;
-    if (q < 16) { src[j] = g.A + piece_src(q, lane, 0, g.M, g.lda); tstep[j] = (long)BM * g.lda; }
+    if (q < 16) { src[j] = g.A + piece_src(q, lane, code0, g.M, g.lda); tstep[j] = (long)BM * g.lda; }
     else { src[j] = g.B + piece_src(q - 16, lane, col0, g.N, g.ldb); tstep[j] = 0; }
     dst[j] = (uint32_t)(q * 1024);
   }
@@ -672,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void vq_topk3_kernel(VqArgs g) {
     if (pre) advance();
     if (++kt == nk) {                                          // a code tile is complete: fold it into the running top-4
       kt = 0;
-      const int row_t = tile * BM + wm * 128;
+      const int row_t = code0 + tile * BM + wm * 128;
       ++tile;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -696,12 +725,12 @@ __global__ __launch_bounds__(512, 2) void vq_topk3_kernel(VqArgs g) {
           }
     }
   }
-  // candidates: [token][ (wm*2 + half) * VQ_TOP + t ]
+  // candidates: [token][code group][ (wm*2 + half) * VQ_TOP + t ]
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = col0 + wn * 64 + j * 32 + lc;
     if (col >= g.N) continue;
-    const long p = (long)col * (4 * VQ_TOP) + (wm * 2 + half) * VQ_TOP;
+    const long p = ((long)col * g.cgroups + cgrp) * (4 * VQ_TOP) + (wm * 2 + half) * VQ_TOP;
 #pragma unroll
     for (int t = 0; t < VQ_TOP; ++t) { g.part_val[p + t] = bv[j][t]; g.part_idx[p + t] = bi[j][t]; }
   }
@@ -810,13 +839,16 @@ extern "C" int ctclip_debug_gemm3_stamps(void* buf, long capacity_blocks) {
 }
 #endif
 
-// called by ctclip_vq_topk (gemm.hip): codes M % 256 == 0, K % 32 == 0; part_val / part_idx are [N][16]
+// called by ctclip_vq_topk / ctclip_vq_topk_grouped (gemm.hip): codes M % 256 == 0, K % 32 == 0, (M / 256) % cgroups == 0;
+// part_val / part_idx are [N][16 * cgroups]
 int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
-                           long ldb, hipStream_t st) {
+                           long ldb, int cgroups, hipStream_t st) {
   using namespace g3;
+  if (cgroups < 1 || cgroups > 32 || (32 % cgroups) || (M / BM) % cgroups) return (int)hipErrorInvalidValue;
   VqArgs g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
-  g.tiles_m = M / BM; g.part_val = part_val; g.part_idx = part_idx;
+  g.cgroups = cgroups; g.ttiles = 32 / cgroups; g.ntok_tiles = (N + 255) / 256;
+  g.tiles_m = M / BM / cgroups; g.part_val = part_val; g.part_idx = part_idx;
   const size_t lds = (size_t)4 * 2 * SUB;          // 128 KiB
   static bool attr_set = false;
   if (!attr_set) {
@@ -824,6 +856,11 @@ int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* p
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(vq_topk3_kernel, dim3((N + 255) / 256), dim3(512), lds, st, g);
+  unsigned grid = (unsigned)g.ntok_tiles;
+  if (cgroups > 1) {
+    const int per_round = 8 * g.ttiles;                               // token tiles the eight XCDs take side by side
+    grid = (unsigned)((g.ntok_tiles + per_round - 1) / per_round) * 8u * 32u;
+  }
+  hipLaunchKernelGGL(vq_topk3_kernel, dim3(grid), dim3(512), lds, st, g);
   return (int)hipGetLastError();
 }

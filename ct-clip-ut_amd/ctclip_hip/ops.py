@@ -793,6 +793,10 @@ class SwapMiddleFn(Function):
         return out
 
 
+# Code groups of the VQ sweep (csrc/gemm3.hip, "CODE GROUPS"): measured at 64 / 88 pairs (profiles/r03_vq_code_groups.txt) the
+# split lowers the fabric traffic by only 30 % (33.4 -> 23.5 GB per launch) and costs 2 - 14 % of time: one group stays the default.
+VQ_CODE_GROUPS = int(_os.environ.get("CTCLIP_VQ_CODE_GROUPS", "1"))
+
 # ---------------------------------------------------------------------------------------------------
 # VQ (cosine-sim codebook, straight-through)            ctvit.py:117-118
 # ---------------------------------------------------------------------------------------------------
@@ -815,10 +819,12 @@ class VQFn(Function):
             ctx.aux = (x2, inv)
             return quant.reshape(b, n, d), idx.reshape(b, n)
         ncodes = embed16.shape[0]
-        ncand = 16                                                # top-4 of each of 4 disjoint quarters of the codebook
+        # 16 candidates per code group = top-4 of each of 4 disjoint parts of the group
+        groups = VQ_CODE_GROUPS if (ncodes % (256 * VQ_CODE_GROUPS) == 0 and d % 32 == 0) else 1
+        ncand = 16 * groups
         pv = torch.empty(M, ncand, dtype=F32, device=x.device)
         pi = torch.empty(M, ncand, dtype=torch.int32, device=x.device)
-        hip.vq_topk(embed16, xn16, pv, pi, ncodes, M, d, embed16.stride(0), xn16.stride(0))
+        hip.vq_topk_grouped(embed16, xn16, pv, pi, ncodes, M, d, embed16.stride(0), xn16.stride(0), groups)
         idx = torch.empty(M, dtype=torch.long, device=x.device)
         quant = torch.empty(M, d, dtype=F32, device=x.device)
         # 2^-7: twice the worst-case bf16 rounding error of a unit-vector dot product -> exact f32 arg-max

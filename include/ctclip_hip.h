@@ -72,6 +72,12 @@ int ctclip_gemm_argmax_partial(const void* A, const void* B, float* part_val, in
  * [N][16] (top-4 of each of 4 disjoint row subsets).  This is the variant the VQ module uses. */
 int ctclip_vq_topk(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda, long ldb,
                    void* stream);
+/* the same search with the codebook split into `code_groups` groups of whole 256-code tiles, the workgroups an XCD holds at a
+ * time sharing token tiles and code tiles through its L2 (csrc/gemm3.hip): part_val/part_idx are [N][16 * code_groups] (top-4 of
+ * each of 4 row subsets of every group); code_groups divides 32 and M / 256, M % 256 == 0, K % 32 == 0.  ctclip_vq_select takes
+ * the wider candidate list as it is.  Call site src/utils/ctvit.py:117-118. */
+int ctclip_vq_topk_grouped(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda, long ldb,
+                           int code_groups, void* stream);
 
 /* ---- LayerNorm: attention.py:27-34 (beta==NULL), attention.py:46, ctvit.py:51, BertLayerNorm ---- */
 int ctclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,

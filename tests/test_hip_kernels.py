@@ -260,6 +260,51 @@ def test_vq_topk_whole_code_tiles(hip, C_, T, K):
     assert int(idx[T - 1]) == 0 and bool(((idx >= 0) & (idx < C_)).all())
 
 
+@pytest.mark.parametrize("C_,T,K,groups", [(1024, 600, 512, 2), (1024, 600, 512, 4), (2048, 2100, 64, 4), (2048, 2100, 64, 8),
+                                           (8192, 300, 64, 32)])
+def test_vq_topk_code_groups(hip, C_, T, K, groups):
+    """ctclip_vq_topk_grouped: the codebook split into code groups, the workgroups an XCD holds at a time being (token tiles x
+    code groups).  Token-tile counts that leave most of the last round of eight XCDs empty, ragged last tiles.  The candidate
+    list [T][16 * groups] must contain everything the one-group list holds, every candidate must carry its own bf16 score, and
+    the exact re-rank must give the same codes as with one group (the true f32 arg-max)."""
+    Ef = torch.nn.functional.normalize(rnd(C_, K, seed=17), dim=-1).contiguous()
+    Xraw = (rnd(T, K, seed=18) * 3).contiguous()
+    for t, (c1, c2) in enumerate([(5, C_ // 2 + 70), (200, 201), (C_ - 1, 3)]):
+        Xraw[t] = (Ef[c1] + Ef[c2]) * 2 + 2e-4 * (Ef[c2] - Ef[c1])
+    inv = 1.0 / Xraw.norm(dim=-1)
+    E, X = bf(Ef), bf(Xraw * inv[:, None])
+    pv1 = torch.full((T, 16), float("nan"), device=DEV)
+    pi1 = torch.full((T, 16), -1, device=DEV, dtype=torch.int32)
+    hip.vq_topk_grouped(E, X, pv1, pi1, C_, T, K, K, K, 1)
+    pv = torch.full((T, 16 * groups), float("nan"), device=DEV)
+    pi = torch.full((T, 16 * groups), -1, device=DEV, dtype=torch.int32)
+    hip.vq_topk_grouped(E, X, pv, pi, C_, T, K, K, K, groups)
+    per = C_ // groups
+    assert bool(((pi >= 0) & (pi < C_)).all()), "every slot holds a code"
+    lo = (torch.arange(groups, device=DEV) * per).repeat_interleave(16)[None]
+    assert bool(((pi >= lo) & (pi < lo + per)).all()), "a group's candidates are codes of that group"
+    assert bool((pi.sort(dim=1).values.diff(dim=1) != 0).all()), "candidates of a token are distinct codes"
+    s16 = X.float() @ E.float().t()
+    check("candidate scores", pv, s16.gather(1, pi.long()), 1e-5)
+    member = (pi1[:, :, None] == pi[:, None, :]).any(dim=2)
+    assert bool(member.all()), "the grouped list contains the one-group list"
+    idx1 = torch.empty(T, dtype=torch.long, device=DEV)
+    idx = torch.empty(T, dtype=torch.long, device=DEV)
+    quant = torch.empty(T, K, device=DEV)
+    hip.vq_select(pv1, pi1, 16, Xraw, inv, Ef, idx1, quant, T, K, 2.0 ** -7)
+    hip.vq_select(pv, pi, 16 * groups, Xraw, inv, Ef, idx, quant, T, K, 2.0 ** -7)
+    exact = (Xraw * inv[:, None]) @ Ef.t()
+    gap = exact.max(dim=1).values - exact.gather(1, idx[:, None])[:, 0]
+    assert float(gap.max()) <= 2e-7 and torch.equal(idx[:3].cpu(), torch.tensor([C_ // 2 + 70, 201, 3]))
+    gap1 = exact.max(dim=1).values - exact.gather(1, idx1[:, None])[:, 0]
+    assert float((gap - gap1).max()) <= 0.0, "more candidates can only move a token to a code at least as near"
+    assert torch.equal(quant, Ef[idx])
+    # 3 / 5 / 33 groups do not divide the 32 workgroups of an XCD or the code tiles: refused, nothing launched
+    for bad in (3, 5, 64):
+        with pytest.raises(RuntimeError):
+            hip.vq_topk_grouped(E, X, pv, pi, C_, T, K, K, K, bad)
+
+
 @pytest.mark.parametrize("nseq,n,H,D,use_bias,use_mask", [
     (3, 128, 4, 64, False, True),      # BERT shape with a padding mask
     (2, 40, 2, 32, True, False),       # ragged rows, dense bias and its gradient
