@@ -44,13 +44,21 @@ __device__ __forceinline__ void load_addend(float (&add)[16], const AttnArgs& a,
         const float4 t = *(const float4*)(brow + k0);
         b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
       } else {
+        // unconditional loads from a clamped index, zeros selected afterwards: a load inside `if (key < n)` is a predicated
+        // block of its own ending in a full wait (see gfrag)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (k0 + i < a.n) b[i] = brow[k0 + i];
+        for (int i = 0; i < 4; ++i) {
+          const float t = brow[k0 + i < a.n ? k0 + i : a.n - 1];
+          b[i] = (k0 + i < a.n) ? t : 0.f;
+        }
       }
     }
     if (mrow) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) if (k0 + i < a.n) b[i] += mrow[k0 + i];
+      for (int i = 0; i < 4; ++i) {
+        const float t = mrow[k0 + i < a.n ? k0 + i : a.n - 1];
+        b[i] += (k0 + i < a.n) ? t : 0.f;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) add[4 * g4 + i] = b[i];

@@ -76,11 +76,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int row0, int s, int 
   return join_tr(lo, hi);
 }
 
-// fragment straight from global memory: element j = M[row][16*s + 8*(lane>>5) + j]
+// fragment straight from global memory: element j = M[row][16*s + 8*(lane>>5) + j]; lanes that are not `valid` get zeros.
+// rowptr must point at a row that EXISTS for every lane (callers clamp the row index): the load is unconditional and the
+// zeros are selected afterwards.  With the load inside `if (valid)` every fragment became its own predicated block that ended
+// in `s_waitcnt vmcnt(0)` -- ten loads of a wave, ten memory round trips one after the other.
 __device__ __forceinline__ bf16x8 gfrag(const bf16_t* __restrict__ rowptr, int s, int lane, bool valid) {
-  short8v z = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (valid) z = *(const short8v*)(rowptr + 16 * s + 8 * (lane >> 5));
-  return as_bf16x8(z);
+  const short8v z = {0, 0, 0, 0, 0, 0, 0, 0};
+  const short8v v = *(const short8v*)(rowptr + 16 * s + 8 * (lane >> 5));
+  return as_bf16x8(valid ? v : z);
 }
 
 // registers 8s..8s+7 of an accumulator -> bf16 fragment of k-step s

@@ -261,6 +261,11 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
 
   load_plane(0, nx);
   __syncthreads();                                           // zero fill + weights visible
+  // the bias row came from a global load: the barrier above has waited for it, but inside the loop the compiler's wait-count
+  // bookkeeping no longer knows how old that load is and put `s_waitcnt vmcnt(0)` in front of every use -- i.e. in front of
+  // each of the six store groups of a step, every one then waiting for the store before it.  A value redefined here has no
+  // load behind it.
+  asm volatile("" : "+v"(bv));
   stage_plane(0);
   if (g.T > 1) load_plane(1, nx);
   __syncthreads();
@@ -394,6 +399,9 @@ __global__ __launch_bounds__(WG_MAXT * WG_C2 / 8, 3) void peg_wgrad_plane_kernel
   for (long b = b0; b < b1; ++b) {
     load_x(b, 0);
     load_dy(b, 0, dcur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // see the end of the t loop: no load is pending on entry either
+#pragma unroll
+    for (int i = 0; i < PL_P; ++i) asm volatile("" : "+v"(nx[i]), "+v"(dcur[i]));
     lds_only_barrier();                                      // the previous item's planes are no longer read
     {
       f32x2 zs[PL_P];
@@ -429,6 +437,13 @@ __global__ __launch_bounds__(WG_MAXT * WG_C2 / 8, 3) void peg_wgrad_plane_kernel
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      // The loads of step t + 1 (issued at the top of this step) are waited for HERE, explicitly, and the registers pass
+      // through an empty asm: left to the compiler's wait-count bookkeeping, the loop-carried dy registers counted as "load
+      // of unknown age pending" at the top of the next step and `s_waitcnt vmcnt(0)` sat right behind the issue of that
+      // step's loads -- nothing was ever in flight during the arithmetic.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < PL_P; ++i) asm volatile("" : "+v"(nx[i]), "+v"(dnext[i]));
       lds_only_barrier();                                    // everybody is done with plane t-2
       if (t + 1 < g.T) put((t + 1) % 3, nx);
       lds_only_barrier();
