@@ -731,7 +731,7 @@ class PatchEmbedFn(Function):
         A = torch.empty(M, ldA, dtype=BF16, device=vol.device)
         mean1 = torch.empty(M, dtype=F32, device=vol.device)
         rstd1 = torch.empty(M, dtype=F32, device=vol.device)
-        hip.patch_ln_fwd(vol, int(is16), sh["ones"], sh["zeros"], A, mean1, rstd1, B, C, Dz, Hy, Wx, tpatch, patch, ldA, 1e-5)
+        hip.patch_ln_fwd(vol, int(is16), None, None, A, mean1, rstd1, B, C, Dz, Hy, Wx, tpatch, patch, ldA, 1e-5)
         z = gemm(A, sh["w"], M, dim, ldA, out_dtype=F32, bias=sh["b"])
         _, y, mean2, rstd2 = layernorm(z, ln2w.detach(), ln2b.detach(), 1e-5, want16=False, want32=True)
         ctx.save_for_backward(vol, A, mean1, rstd1, z, mean2, rstd2, ln2w)

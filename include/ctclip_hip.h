@@ -215,7 +215,8 @@ int ctclip_peg_bwd_weight(const float* dy, const float* x, float* dw27, float* d
                           float* partials, void* stream);
 
 /* ---- tubelet gather + LayerNorm(c*pt*p*p) -> bf16 GEMM operand [tokens, ldA] (ctvit.py:44-49) ----
- * volume: [B,C,Dz,Hy,Wx] f32 or bf16; pad columns F..ldA-1 are written as zero. */
+ * volume: [B,C,Dz,Hy,Wx] f32 or bf16; pad columns F..ldA-1 are written as zero.  gamma == NULL (then beta is ignored): the
+ * plain normalised rows, for callers that fold the affine part into the projection (ctclip_patch_affine_fold). */
 int ctclip_patch_ln_fwd(const void* volume, int volume_is_bf16, const float* gamma, const float* beta, void* A_bf16,
                         float* mean, float* rstd, int B, int C, int Dz, int Hy, int Wx, int pt, int p, long ldA,
                         float eps, void* stream);

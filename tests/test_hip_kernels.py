@@ -806,6 +806,13 @@ def test_patch_ln_forward_and_volume_gradient(hip, in16, geom):
     mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
     hip.patch_ln_fwd(vol, int(in16), gm, bt, A, mean, rstd, B, C, Dz, Hy, Wx, pt, p, ldA, 1e-5)
     check("patch ln A", A, ref, 1e-2)
+    # gamma == NULL: the plain normalised rows (what the folded projection consumes), bit-equal to gamma = 1, beta = 0
+    A0, A1 = torch.empty_like(A), torch.empty_like(A)
+    hip.patch_ln_fwd(vol, int(in16), None, None, A0, mean, rstd, B, C, Dz, Hy, Wx, pt, p, ldA, 1e-5)
+    hip.patch_ln_fwd(vol, int(in16), torch.ones(F_, device=DEV), torch.zeros(F_, device=DEV), A1, mean, rstd, B, C, Dz, Hy, Wx, pt, p,
+                     ldA, 1e-5)
+    assert torch.equal(A0, A1)
+    check("patch ln A (no affine)", A0, torch.nn.functional.layer_norm(rows.detach(), (F_,), None, None, 1e-5), 1e-2)
     dA = bf(rnd(M, ldA, seed=53))
     ref.backward(dA.float())
     dvol = torch.empty(B, C, Dz, Hy, Wx, device=DEV)

@@ -22,6 +22,12 @@ def timeit(fn, n=5):
 gb = (vol.numel() * 2 + A.numel() * 2) / 1e9
 t = timeit(lambda: hip.patch_ln_fwd(vol, 1, gm, bt, A, mean, rstd, B, 1, 240, 480, 480, 10, 20, F_, 1e-5))
 print(f"patch_ln_fwd {t:9.1f} us  {gb / t * 1e6 / 1e3:5.2f} TB/s")
+if os.environ.get("NULL_AFFINE", "1") == "1":
+    try:
+        t = timeit(lambda: hip.patch_ln_fwd(vol, 1, None, None, A, mean, rstd, B, 1, 240, 480, 480, 10, 20, F_, 1e-5))
+        print(f"patch_ln_fwd (no affine: folded into the projection) {t:9.1f} us  {gb / t * 1e6 / 1e3:5.2f} TB/s")
+    except Exception as e:                                     # an older library build
+        print("patch_ln_fwd without affine: not supported by this build", type(e).__name__)
 G, W = torch.randn(512, F_, device="cuda"), torch.randn(512, F_, device="cuda")
 dW, dbv = torch.zeros(512, F_, device="cuda"), torch.randn(512, device="cuda")
 t = timeit(lambda: hip.patch_affine_bwd(G, dbv, W, gm, bt, dW, dg, db, 512, F_))
