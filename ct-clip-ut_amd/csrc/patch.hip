@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void patch_ln_fwd_kernel(const TIN* __restrict
   float* smean = (float*)(smem + (size_t)g.tpb * g.F * sizeof(TIN));
   float* srstd = smean + g.tpb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;                      // (an XCD-contiguous order of the workgroups that share a volume row: 5050 -> 5130 us)
+  int bid = blockIdx.x;
   const int wg = bid % g.wgroups; bid /= g.wgroups;
   const int h = bid % g.Ht; bid /= g.Ht;
   const int t = bid % g.Tt;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void patch_ln_bwd_dx_kernel(const TIN* __restr
   float* sm1 = (float*)(smem + (size_t)g.tpb * g.F * sizeof(TIN));
   float* sm2 = sm1 + g.tpb;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bid = blockIdx.x;                      // (an XCD-contiguous order of the workgroups that share a volume row: 5050 -> 5130 us)
+  int bid = blockIdx.x;
   const int wg = bid % g.wgroups; bid /= g.wgroups;
   const int h = bid % g.Ht; bid /= g.Ht;
   const int t = bid % g.Tt;
