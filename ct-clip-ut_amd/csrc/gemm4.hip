@@ -18,6 +18,32 @@
 
 namespace g4 {
 
+#ifdef CTCLIP_G4_STAMPS
+// diagnostic build only (hipcc -DCTCLIP_G4_STAMPS; never compiled into the shipped library), read by tools/gemm4_timeline.py:
+// per-workgroup phase stamps {hw id, xcc id, start, first K-step landed, matrix loop done, stores drained, stores issued} in
+// 10 ns ticks, and per-segment shader-cycle sums of the matrix loop for waves 0 (wm = 0) and 4 (wm = 1)
+__device__ unsigned long long* g_stamps = nullptr;
+__device__ unsigned long long* g_prof = nullptr;   // [blocks][16]
+__device__ long g_stamp_cap = 0;
+#define G4_STAMP(slot)                                                                                            \
+  do {                                                                                                            \
+    if (g_stamps && threadIdx.x == 0 && (long)blockIdx.x < g_stamp_cap)                                           \
+      g_stamps[(long)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                                 \
+  } while (0)
+#define G4_SEG_DECL() unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long c_ = __builtin_amdgcn_s_memtime()
+#define G4_SEG(n) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg_[n] += t_ - c_; c_ = t_; } while (0)
+#define G4_SEG_STORE()                                                                                            \
+  do {                                                                                                            \
+    if (g_prof && (threadIdx.x == 0 || threadIdx.x == 256) && (long)blockIdx.x < g_stamp_cap)                    \
+      for (int n_ = 0; n_ < 8; ++n_) g_prof[(long)blockIdx.x * 16 + (threadIdx.x >> 8) * 8 + n_] = seg_[n_];     \
+  } while (0)
+#else
+#define G4_STAMP(slot) do { } while (0)
+#define G4_SEG_DECL() do { } while (0)
+#define G4_SEG(n) do { } while (0)
+#define G4_SEG_STORE() do { } while (0)
+#endif
+
 constexpr int BM = 256, BN = 256, BK = 32, NS = 4, NT = 512;
 constexpr int SUB = 16384;                 // one operand tile of a stage: 32 k-rows x 256 columns of bf16
 constexpr int STAGE = 2 * SUB;
@@ -98,6 +124,13 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
   const int nk_total = g.K / BK;
   const int kt_begin = ks * g.ktiles_per_split;
   const int nk = min(nk_total, kt_begin + g.ktiles_per_split) - kt_begin;
+#ifdef CTCLIP_G4_STAMPS
+  if (g_stamps && threadIdx.x == 0 && (long)blockIdx.x < g_stamp_cap) {
+    g_stamps[(long)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+    g_stamps[(long)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+  }
+#endif
+  G4_STAMP(2);
 
   // piece q = wave * PPW + j of a stage: the first 16 are the A tile, the rest the B tile (stored right behind it)
   const bf16_t* src[PPW];
@@ -226,30 +259,49 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   G4_BAR();
+  G4_STAMP(3);
+  G4_SEG_DECL();
+  // profiled segments: 0 load block issue (24 transposed reads + 4 DMA pieces), 1 lgkmcnt wait, 2 barrier after the load block,
+  // 3 MFMA block, 4 vmcnt wait, 5 barrier after the MFMA block
   if (wm == 0) {
     for (int k = 0; k < nk; ++k) {
       load_block(k);
+      G4_SEG(0);
       tr_wait(r0);
       tr_wait(r1);
+      G4_SEG(1);
       G4_BAR();
+      G4_SEG(2);
       mfma_block();
+      G4_SEG(3);
       wait_next(k);
+      G4_SEG(4);
       G4_BAR();
+      G4_SEG(5);
     }
     G4_BAR();                                       // the other half's last MFMA block
   } else {
     G4_BAR();                                       // interval 0: the other half reads stage 0
+    G4_SEG(6);
     for (int k = 0; k < nk; ++k) {
       load_block(k);
+      G4_SEG(0);
       wait_next(k);
+      G4_SEG(4);
       tr_wait(r0);
       tr_wait(r1);
+      G4_SEG(1);
       G4_BAR();
+      G4_SEG(2);
       mfma_block();
+      G4_SEG(3);
       G4_BAR();
+      G4_SEG(5);
     }
   }
 #undef G4_BAR
+  G4_SEG_STORE();
+  G4_STAMP(4);
 
 
   // split-K: f32 atomics straight from the accumulators.  For a fixed register the 64 lanes cover two 128-byte row
@@ -272,6 +324,11 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
           else atomicAdd(g.C + (long)row * g.ldc + col, v);
         }
       }
+    G4_STAMP(6);                                      // every store of wave 0 issued
+#ifdef CTCLIP_G4_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and drained
+#endif
+    G4_STAMP(5);
     return;
   }
   const int half = lane >> 5, lc = lane & 31;
@@ -290,9 +347,27 @@ __global__ __launch_bounds__(NT, 2) void gemm4_kernel(Args g) {
         else atomicAdd(g.C + (long)row * g.ldc + col, v);
       }
     }
+  G4_STAMP(6);
+#ifdef CTCLIP_G4_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  G4_STAMP(5);
 }
 
 }  // namespace g4
+
+#ifdef CTCLIP_G4_STAMPS
+extern "C" int ctclip_debug_gemm4_prof(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g4::g_prof), &p, sizeof(p));
+}
+extern "C" int ctclip_debug_gemm4_stamps(void* buf, long capacity_blocks) {
+  unsigned long long* p = (unsigned long long*)buf;
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g4::g_stamps), &p, sizeof(p));
+  if (e != hipSuccess) return (int)e;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g4::g_stamp_cap), &capacity_blocks, sizeof(capacity_blocks));
+}
+#endif
 
 // called by ctclip_gemm_bf16 (gemm.hip): m-major x n-major, K % 32 == 0, f32 accumulate output
 int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
