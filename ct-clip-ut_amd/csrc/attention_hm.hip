@@ -33,6 +33,15 @@
 // wave with 16 or 12 waves (K / V fetched twice as often: 1437 / 1412 us), touching the wave's next sequence in L2 one
 // sequence ahead (1137 us: the first touch is not what the tiles wait for).
 #include "attn_common.h"
+#ifndef HM_STAMPS
+#define HM_STAMPS 0                   // diagnostic build: per-wave cycle totals of the forward's phases (tools/bench_attn_hm.py STAMPS=1)
+#endif
+#ifndef HM_BIAS_C
+#define HM_BIAS_C 1                   // forward: bias tile through the score MFMA's C operand (0: the f16 identity product)
+#endif
+#ifndef HM_ABL
+#define HM_ABL 0                      // timing-only ablations of the forward (tools/build_variant.sh); 0 in every product build
+#endif
 
 namespace {
 
@@ -107,6 +116,42 @@ __device__ __forceinline__ void fill_bias(half8* bl, const float* __restrict__ b
   }
 }
 
+// The workgroups of the SHORT last chunk go first in dispatch order.  Workgroups are handed out in block order, so as the last
+// blocks they started only when round 2 had ended -- 72 workgroups with 3 sequences per wave holding the launch for another
+// 90 us of 1215 (stamped: start times 0 / 560-576 / 1122-1158 us at 1536 sequences) -- as the first ones they are gone after
+// a tenth of a round and their CUs take full-size chunks.
+__device__ __forceinline__ int hm_chunk_order(int logical, int nchunks) { return logical == 0 ? nchunks - 1 : logical - 1; }
+
+// Sequences are handed out to the waves of a workgroup from a counter in LDS: with the static assignment (wave w takes
+// seq0 + w, + NW, ...) the waves of a workgroup ended up to 16 % apart (767k .. 1061k cycles of wave life around a mean of
+// 902k) and the CU waited for the slowest one.
+__device__ __forceinline__ int hm_next_seq(int* counter, int lane) {
+  int v = 0;
+  if (lane == 0) v = atomicAdd(counter, 1);
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// The same fp16 bias tiles in ACCUMULATOR layout (forward, HM_BIAS_C): cfrag[((b * T + t) * 2 + u) * 64 + lane], element j =
+// bias[own0 + 32 b + (lane & 31)][32 t + 8 (2 u + (j >> 2)) + 4 (lane >> 5) + (j & 3)] * log2(e) -- registers 8 u .. 8 u + 7 of
+// the lane's S^T accumulator.  The tile is unpacked by the VALU (16 v_cvt_f32_f16) and enters the first score MFMA as its C
+// operand: two MFMAs fewer per score tile than the identity product.  The kernels run against the power limit (the shader
+// clock sits at 1.6-1.8 GHz and falls when stalls are removed), and a 32x32x16 MFMA costs far more energy than 16 conversions.
+__device__ __forceinline__ void fill_bias_c(half8* bl, const float* __restrict__ bias_h, int n, int own0, int nown, int NB, int T,
+                                            int tid, int nthreads) {
+  for (int id = tid; id < NB * T * 128; id += nthreads) {
+    const int l = id & 63, u = (id >> 6) & 1, bt = id >> 7, t = bt % T, b = bt / T;
+    half8 hv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hv[j] = (_Float16)0.f;
+    if (b < nown) {
+      const float* bp = bias_h + (long)(own0 + 32 * b + (l & 31)) * n + 32 * t + 16 * u + 4 * (l >> 5);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hv[j] = (_Float16)(bp[8 * (j >> 2) + (j & 3)] * kLog2e);
+    }
+    bl[id] = hv;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
@@ -130,17 +175,21 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
   int L = xcd_remap(blockIdx.x, gridDim.x);
   const int grp = L % G;
   L /= G;
-  const int chunk_id = L % a.nchunks, head = L / a.nchunks;
+  const int chunk_id = hm_chunk_order(L % a.nchunks, a.nchunks), head = L / a.nchunks;
   const int seq0 = chunk_id * a.chunk, seq1 = min(a.nseq, seq0 + a.chunk);
   const int nqb = min(QB, T - grp * QB);
   const int q0 = grp * QB * 32;
 
   half8* bias_l = (half8*)smem;                                    // [QB][T][2][64] half8
   char* vimg = smem + (size_t)(HAS_BIAS ? QB * T : 0) * 2048 + (size_t)w * 4096;   // wave-private: 2 x [32 keys][32 d] bf16
-  if (HAS_BIAS) {
-    fill_bias<true>(bias_l, a.bias + (long)head * a.n * a.n, a.n, q0, nqb, QB, T, tid, NW * 64);
-    __syncthreads();
-  }
+  __shared__ int seq_counter;
+  if (tid == 0) seq_counter = seq0;
+#if HM_BIAS_C
+  if (HAS_BIAS) fill_bias_c(bias_l, a.bias + (long)head * a.n * a.n, a.n, q0, nqb, QB, T, tid, NW * 64);
+#else
+  if (HAS_BIAS) fill_bias<true>(bias_l, a.bias + (long)head * a.n * a.n, a.n, q0, nqb, QB, T, tid, NW * 64);
+#endif
+  __syncthreads();
   half8 idf[2];
   identity_frags(idf, r, half);
   const f32x16 zero16 = splat16(0.f);
@@ -151,28 +200,60 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
   const uint32_t vst = img_off<32>(crow, ccol);                    // + 1024: sixteen rows further, same swizzle
   const long hstride = (long)a.n * 32;
 
-  for (int seq = seq0 + w; seq < seq1; seq += NW) {
-    const long base = ((long)seq * a.heads + head) * hstride;
-    const bf16_t* kb = a.k + base + koff;
-    const bf16_t* vb = a.v + base + voff;
-    const bf16_t* qb = a.q + base + qoff;
-    bf16x8 qf[QB][2];
+#if HM_STAMPS
+  long long c_pro = 0, c_loop = 0, c_epi = 0, c_n = 0;
+  const long long c_start = __builtin_readcyclecounter();
+  const long long r_start = __builtin_amdgcn_s_memrealtime();
+#endif
+  // The K / V tile stream and the q fragments run ACROSS sequences: the last two requests of a sequence fetch the first two
+  // tiles of the wave's NEXT sequence (taken from the counter one sequence ahead) and its q rows are requested before the
+  // epilogue, so a sequence no longer starts with a memory round trip (stamped: prologue 1.7-2.0k + epilogue 2.1-2.7k of
+  // 27-33k cycles per sequence).
+  bf16x8 qf[QB][2];
+  bf16x8 kr[2][2];
+  u32x4 vr[2][2];
+  auto seq_base = [&](int sq) { return ((long)sq * a.heads + head) * hstride; };
+  auto load_q = [&](long base) {
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-      const bf16_t* qp = qb + (uint32_t)(b < nqb ? b : 0) * 1024;  // a short last group re-reads block 0 (results discarded)
+      const bf16_t* qp = a.q + base + qoff + (uint32_t)(b < nqb ? b : 0) * 1024;   // a short last group re-reads block 0 (results discarded)
       qf[b][0] = as_bf16x8(*(const short8v*)qp);
       qf[b][1] = as_bf16x8(*(const short8v*)(qp + 16));
     }
-    bf16x8 kr[2][2];
-    u32x4 vr[2][2];
-    auto request = [&](int slot, int t) {
-      kr[slot][0] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * 1024));
-      kr[slot][1] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * 1024 + 16));
-      vr[slot][0] = *(const u32x4*)(vb + (uint32_t)t * 1024);
-      vr[slot][1] = *(const u32x4*)(vb + (uint32_t)t * 1024 + 512);
-    };
-    request(0, 0);
-    if (T > 1) request(1, 1);
+  };
+  auto request = [&](int slot, long base, int t) {
+    const bf16_t* kp = a.k + base + koff + (uint32_t)t * 1024;
+    const bf16_t* vp = a.v + base + voff + (uint32_t)t * 1024;
+    kr[slot][0] = as_bf16x8(*(const short8v*)kp);
+    kr[slot][1] = as_bf16x8(*(const short8v*)(kp + 16));
+    vr[slot][0] = *(const u32x4*)vp;
+    vr[slot][1] = *(const u32x4*)(vp + 512);
+  };
+  int seq = hm_next_seq(&seq_counter, lane);
+  if (seq < seq1) {
+    const long b0 = seq_base(seq);
+    load_q(b0);
+    request(0, b0, 0);
+    request(1, b0, T > 1 ? 1 : 0);
+  }
+  while (seq < seq1) {
+#if HM_STAMPS
+    const long long c0 = __builtin_readcyclecounter();
+#endif
+    const int nxt = hm_next_seq(&seq_counter, lane);
+    const long base = seq_base(seq);
+    const long nbase = seq_base(nxt < seq1 ? nxt : seq);           // no next sequence: re-read this one's first tiles (dropped)
+    // q (requested before the previous epilogue's stores) must be here now; say so ONCE -- left to the compiler's wait-count
+    // bookkeeping the q registers count as "a load of unknown age" at the head of the tile loop and every trip waits with
+    // vmcnt(1), draining the K / V request it has just issued.  Everything older (both K / V slots) has arrived as well.
+    // (This also waits for the previous epilogue's stores, the youngest operations.  Waiting for everything BUT them --
+    // asm stores, an exact vmcnt(10) -- does not survive the compiler: it knows nothing of asm stores and puts its own,
+    // smaller count in front of the first use of every loaded register.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int b = 0; b < QB; ++b) asm volatile("" : "+v"(qf[b][0]), "+v"(qf[b][1]));
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) asm volatile("" : "+v"(kr[sl][0]), "+v"(kr[sl][1]), "+v"(vr[sl][0]), "+v"(vr[sl][1]));
     float m[QB], l[QB];
     f32x16 O[QB];
 #pragma unroll
@@ -180,13 +261,30 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
 
     auto tile = [&](int slot, int t) {
       char* vi = vimg + (t & 1) * 2048;
+#if !(HM_ABL & 16)
       *(u32x4*)(vi + vst) = vr[slot][0];
       *(u32x4*)(vi + vst + 1024) = vr[slot][1];
+#endif
       const bf16x8 k0 = kr[slot][0], k1 = kr[slot][1];
-      if (t + 2 < T) request(slot, t + 2);                         // this slot's registers are free again
+#if HM_ABL & 16
+      const bf16x8 vt0 = k0, vt1 = k1;
+#else
       const bf16x8 vt0 = tr_frag<32>(vi, 0, 0, 0, lane), vt1 = tr_frag<32>(vi, 0, 1, 0, lane);
+#endif
       f32x16 S[QB];
-      if (HAS_BIAS) {
+#if HM_BIAS_C
+      if (HAS_BIAS && !(HM_ABL & 4)) {
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+          const half8 c0 = bias_l[((b * T + t) * 2 + 0) * 64 + lane], c1 = bias_l[((b * T + t) * 2 + 1) * 64 + lane];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { S[b][j] = (float)c0[j]; S[b][8 + j] = (float)c1[j]; }
+        }
+#pragma unroll
+        for (int b = 0; b < QB; ++b) S[b] = mfma32(k0, qf[b][0], S[b]);
+      } else
+#endif
+      if (HAS_BIAS && !(HM_ABL & 4)) {
 #pragma unroll
         for (int b = 0; b < QB; ++b) S[b] = mfma32h(bias_l[((b * T + t) * 2 + 0) * 64 + lane], idf[0], zero16);
 #pragma unroll
@@ -200,13 +298,27 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
 #pragma unroll
       for (int b = 0; b < QB; ++b) S[b] = mfma32(k1, qf[b][1], S[b]);
       __builtin_amdgcn_sched_barrier(0);
+      // Request this slot's next tile AFTER the score MFMAs have read it (requested before them, the compiler parks k1 in
+      // spare registers early -- a copy that waits for the OTHER slot's load, one tile ahead of its use).  UNCONDITIONAL:
+      // behind a branch the wait-count bookkeeping no longer knows how many loads are in flight and waits for all of them.
+#if !(HM_ABL & 2)
+      {
+        const bool cur = t + 2 < T;                                // else: tile `slot` of the NEXT sequence lives in this slot
+        request(slot, cur ? base : nbase, cur ? t + 2 : (slot < T ? slot : 0));
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < QB; ++b) {
         if (STATIC) {
           float l0 = 0.f, l1 = 0.f;
 #pragma unroll
           for (int i = 0; i < 16; i += 2) {
+#if HM_ABL & 1
+            const float e0 = S[b][i], e1 = S[b][i + 1];
+#else
             const float e0 = exp2_fast(S[b][i]), e1 = exp2_fast(S[b][i + 1]);
+#endif
             S[b][i] = e0; S[b][i + 1] = e1;
             l0 += e0; l1 += e1;
           }
@@ -232,16 +344,28 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
           }
         }
         const bf16x8 p0 = acc_frag(S[b], 0), p1 = acc_frag(S[b], 1);
+#if HM_ABL & 8
+        O[b][0] += (float)p0[0] + (float)p1[0] + (float)vt0[0] + (float)vt1[0];
+#else
         O[b] = mfma32(vt0, p0, O[b]);
         O[b] = mfma32(vt1, p1, O[b]);
+#endif
       }
     };
+#if HM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long c1 = __builtin_readcyclecounter();
+#endif
     int t = 0;
     for (; t + 1 < T; t += 2) {                                    // two tiles per trip: the V image alternates, slots are static
       tile(0, t);
       tile(1, t + 1);
     }
     if (t < T) tile(0, t);
+#if HM_STAMPS
+    const long long c2 = __builtin_readcyclecounter();
+#endif
+    load_q(nbase);                                                 // in flight under the epilogue
 
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
@@ -253,7 +377,20 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
       store_rows<32>(a.o + row * a.ldo + head * 32, oo, 1.0f / lt, lane);
       if (half == 0) a.lse[((long)seq * a.heads + head) * a.n + q] = ((STATIC ? 0.f : m[b]) + __log2f(lt)) * kLn2;
     }
+#if HM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long c3 = __builtin_readcyclecounter();
+    c_pro += c1 - c0; c_loop += c2 - c1; c_epi += c3 - c2; c_n += 1;
+#endif
+    seq = nxt;
   }
+#if HM_STAMPS
+  if (lane == 0) {                                                 // beyond the real lse: [block][wave][8] floats (the bench allocates it)
+    float* st = a.lse + (long)a.nseq * a.heads * a.n + ((long)blockIdx.x * NW + w) * 8;
+    st[0] = (float)c_pro; st[1] = (float)c_loop; st[2] = (float)c_epi; st[3] = (float)c_n;
+    st[4] = (float)(c_start & 0xffffff); st[5] = (float)(__builtin_readcyclecounter() - c_start); st[6] = (float)(__builtin_amdgcn_s_memrealtime() - r_start); st[7] = (float)(r_start & 0xffffff);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -277,7 +414,7 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
   int L = xcd_remap(blockIdx.x, gridDim.x);
   const int grp = L % G;
   L /= G;
-  const int chunk_id = L % a.nchunks, head = L / a.nchunks;
+  const int chunk_id = hm_chunk_order(L % a.nchunks, a.nchunks), head = L / a.nchunks;
   const int seq0 = chunk_id * a.chunk, seq1 = min(a.nseq, seq0 + a.chunk);
   const int nqb = min(QB, T - grp * QB);
   const int q0 = grp * QB * 32;
@@ -298,7 +435,9 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
     for (int id = tid; id < T; id += NW * 64) lock_l[id] = 0u;
   }
   if (HAS_BIAS) fill_bias<true>(bias_l, a.bias + (long)head * a.n * a.n, a.n, q0, nqb, QB, T, tid, NW * 64);
-  if (HAS_BIAS || DBL) __syncthreads();
+  __shared__ int seq_counter;
+  if (tid == 0) seq_counter = seq0;
+  __syncthreads();
   half8 idf[2];
   identity_frags(idf, r, half);
   half8 ones01;                                                    // A fragment of ones[key][k], k in {0, 1}
@@ -316,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
   const int rot = DBL ? (w * T) / NW : 0;                          // this wave's first key tile
   auto phys = [&](int it) { const int t = it + rot; return t >= T ? t - T : t; };
 
-  for (int seq = seq0 + w; seq < seq1; seq += NW) {
+  for (int seq = hm_next_seq(&seq_counter, lane); seq < seq1; seq = hm_next_seq(&seq_counter, lane)) {
     const long base = ((long)seq * a.heads + head) * hstride;
     const bf16_t* kb = a.k + base + kvoff;
     const bf16_t* vb = a.v + base + kvoff;
@@ -328,7 +467,7 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
       vr[slot][1] = as_bf16x8(*(const short8v*)(vb + (uint32_t)t * 1024 + kvstep));
     };
     request(0, phys(0));
-    if (T > 1) request(1, phys(1));
+    request(1, phys(T > 1 ? 1 : 0));                               // unconditional: see the forward's request
     bf16x8 qf[QB][2], df[QB][2];
     float nlse2[QB], delta[QB];
     f32x16 dq[QB];
@@ -438,7 +577,7 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) *(volatile unsigned*)lk = 0u;
       }
-      if (it + 2 < T) request(slot, phys(it + 2));                 // a whole tile of work ahead of its use
+      request(slot, phys(it + 2 < T ? it + 2 : T - 1));            // a whole tile of work ahead of its use (unconditional)
     };
     int t = 0;
     for (; t + 1 < T; t += 2) {
@@ -504,7 +643,7 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dkv_kernel(HmArgs a) {
   int L = xcd_remap(blockIdx.x, gridDim.x);
   const int grp = L % G;
   L /= G;
-  const int chunk_id = L % a.nchunks, head = L / a.nchunks;
+  const int chunk_id = hm_chunk_order(L % a.nchunks, a.nchunks), head = L / a.nchunks;
   const int seq0 = chunk_id * a.chunk, seq1 = min(a.nseq, seq0 + a.chunk);
   const int nkb = min(KB, T - grp * KB);
   const int key0 = grp * KB * 32;
@@ -514,10 +653,10 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dkv_kernel(HmArgs a) {
   char* qimg = wave_l;                                             // [32 q][32 d] bf16
   char* doimg = wave_l + 2048;                                     // [32 q][32 d] bf16
   float* stat_l = (float*)(wave_l + 4096);                         // [n] -lse log2e, [n] -delta
-  if (HAS_BIAS) {
-    fill_bias<false>(bias_l, a.bias + (long)head * a.n * a.n, a.n, key0, nkb, KB, T, tid, NW * 64);
-    __syncthreads();
-  }
+  __shared__ int seq_counter;
+  if (tid == 0) seq_counter = seq0;
+  if (HAS_BIAS) fill_bias<false>(bias_l, a.bias + (long)head * a.n * a.n, a.n, key0, nkb, KB, T, tid, NW * 64);
+  __syncthreads();
   half8 idf[2];
   identity_frags(idf, r, half);
 
@@ -526,7 +665,7 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dkv_kernel(HmArgs a) {
   const uint32_t ist0 = img_off<32>(r, half), ist1 = img_off<32>(r, 2 + half);
   const long hstride = (long)a.n * 32;
 
-  for (int seq = seq0 + w; seq < seq1; seq += NW) {
+  for (int seq = hm_next_seq(&seq_counter, lane); seq < seq1; seq = hm_next_seq(&seq_counter, lane)) {
     const long base = ((long)seq * a.heads + head) * hstride;
     const bf16_t* qb = a.q + base + qoff;
     const bf16_t* dob = a.dO + base + qoff;
@@ -549,7 +688,7 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dkv_kernel(HmArgs a) {
       vf[b][1] = as_bf16x8(*(const short8v*)(vp + 16));
     }
     request(0, 0);
-    if (T > 1) request(1, 1);
+    request(1, T > 1 ? 1 : 0);                                     // unconditional: see the forward's request
     {
       const long stat = ((long)seq * a.heads + head) * a.n;
       for (int i = lane; i < a.n; i += 64) {
@@ -601,7 +740,7 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dkv_kernel(HmArgs a) {
         dk[b] = mfma32(qt1, d1, dk[b]);
         __builtin_amdgcn_sched_barrier(0);                         // one block's temporaries live at a time
       }
-      if (t + 2 < T) request(slot, t + 2);                         // a whole tile of work ahead of its use
+      request(slot, t + 2 < T ? t + 2 : T - 1);                    // a whole tile of work ahead of its use (unconditional)
     };
     int t = 0;
     for (; t + 1 < T; t += 2) {
@@ -687,8 +826,11 @@ void hm_plan(HmArgs& p, int qb, int nw, int* nblocks) {
     const double fill = (double)(roles * nf) / (double)(rr * cus);
     if (fill > best + 0.02) { best = fill; nfull = nf; }           // the fewest rounds among (nearly) equally tight fits
   }
-  long chunk = nfull > 0 ? p.nseq / nfull : p.nseq;
-  chunk = chunk / nw * nw;                                         // every wave of a workgroup the same number of sequences
+  // sequences are handed out to the waves dynamically (hm_next_seq), so a chunk need not be a multiple of the wave count:
+  // nfull (nearly) equal chunks and NO short one.  With chunks rounded down to whole waves (216 of 1536 / 7 = 219.4) the
+  // remainder made an eighth, short chunk whose workgroups either ended the launch alone or, dispatched first, pushed a
+  // quarter of the full-size ones 78 us back: 1157 us where two rounds of 7 x 220 take ~1030
+  long chunk = nfull > 0 ? (p.nseq + nfull - 1) / nfull : p.nseq;
   if (chunk < nw) {                                                // few sequences: as many chunks as fill ~8 rounds
     long nchunks = (8 * cus + roles - 1) / roles;
     if (nchunks < 1) nchunks = 1;
