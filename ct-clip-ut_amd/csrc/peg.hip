@@ -10,6 +10,9 @@
 // dsconv.weight[d,1,3,3,3]) so that a wave reads one coalesced row per tap.
 #include "common.h"
 #include <stdlib.h>
+#ifndef PEG_STAMPS
+#define PEG_STAMPS 0                // diagnostic build: per-wave cycle totals of the plane sweep's phases (tools/bench_peg.py STAMPS=1)
+#endif
 
 namespace {
 
@@ -269,9 +272,21 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
   stage_plane(0);
   if (g.T > 1) load_plane(1, nx);
   __syncthreads();
+#if PEG_STAMPS
+  long long cs[6] = {0, 0, 0, 0, 0, 0};
+  const long long c_begin = __builtin_readcyclecounter();
+  const long long r_begin = __builtin_amdgcn_s_memrealtime();
+#define PEG_ST(i) { const long long c_ = __builtin_readcyclecounter(); cs[i] += c_ - c_last; c_last = c_; }
+#else
+#define PEG_ST(i)
+#endif
   for (int tp = 0; tp < g.T; ++tp) {
+#if PEG_STAMPS
+    long long c_last = __builtin_readcyclecounter();
+#endif
     const int buf = tp & 1;
     if (tp + 2 < g.T) load_plane(tp + 2, nx2);               // in flight while this plane and the next are consumed
+    PEG_ST(0)
     const f32x4* pb = plane + buf * plane_f4;
     int wofs = 0;
     asm volatile("" : "+s"(wofs));                           // opaque zero: keeps the 27 weight reads inside the loop
@@ -306,19 +321,32 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    PEG_ST(1)
     const int tout = FWD ? tp : tp - 2;
     if (tout >= 0) store_row(tout, acc[0]);
+    PEG_ST(2)
 #pragma unroll
     for (int i = 0; i < PL_P; ++i) { acc[0][i] = acc[1][i]; acc[1][i] = acc[2][i]; acc[2][i] = zero; }
     if (tp + 1 < g.T) stage_plane(buf ^ 1);
 #pragma unroll
     for (int i = 0; i < PL_P; ++i) nx[i] = nx2[i];
+    PEG_ST(3)
     lds_only_barrier();
+    PEG_ST(4)
   }
   if (!FWD) {
     if (g.T >= 2) store_row(g.T - 2, acc[0]);
     store_row(g.T - 1, acc[1]);
   }
+#if PEG_STAMPS
+  if ((tid & 63) == 0 && y) {                                 // beyond the real output: [block][wave][8] floats (the bench allocates it)
+    float* st = y + (long)g.B * g.T * g.H * g.W * g.d4 * 4 + ((long)blockIdx.x * (PL_MAXT / 64) + (tid >> 6)) * 8;
+    for (int i = 0; i < 5; ++i) st[i] = (float)cs[i];
+    st[5] = (float)(__builtin_readcyclecounter() - c_begin);
+    st[6] = (float)(__builtin_amdgcn_s_memrealtime() - r_begin);
+    st[7] = (float)(r_begin & 0xffffff);
+  }
+#endif
 }
 
 // plane path geometry: threads (multiple of 64) or 0 when the plane does not fit a workgroup / LDS
