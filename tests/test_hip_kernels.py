@@ -626,11 +626,17 @@ def test_headnorm_and_gemm_write_head_major(hip):
     (7, 160, 3, True, 3),       # 5 tiles: a half-empty last group; three sequences per workgroup + a ragged last chunk
     (4, 96, 4, False, 0),       # no bias
     (3, 640, 1, True, 0),       # 20 tiles: the d(bias) pass has room for 8 waves only
+    (37, 96, 2, True, 5),       # ODD tile count (3) with the operand stream running across sequences (the next sequence's first
+                                # tiles land in the slots by parity), five sequences per workgroup handed out from the LDS counter
+    (19, 32, 2, True, 0),       # ONE tile per sequence: every request of a sequence is already the next sequence's
+    (41, 64, 1, True, 7),       # two tiles, chunks that are no multiple of the wave count, one head
 ])
 def test_head_major_attention_fwd_bwd(hip, nseq, n, H, use_bias, chunk, monkeypatch):
     """ctclip_attn_hm_fwd / _bwd (csrc/attention_hm.hip) against f32 torch on the same bf16-rounded operands: log2-domain
     logits (q carries scale * log2 e, natural logit = ln2 * q.k + bias), no-maximum softmax under ctclip_attn_shift's bound, bias
-    through the f16 identity MFMA, out / lse / dq / dk / dv and d(bias) in its dense, index-table and 2-D grid forms.
+    through the score MFMA's C operand (forward) / the f16 identity MFMA (backward), sequences handed out to the waves from an
+    LDS counter with the K / V / q stream running across them, out / lse / dq / dk / dv and d(bias) in its dense, index-table
+    and 2-D grid forms.
     Also: the online-softmax kernel of the launch pair (no shift, and a shift flagged unsafe) gives the same result."""
     D, LOG2E, LN2 = 32, 1.4426950408889634, 0.6931471805599453
     if chunk:
