@@ -504,6 +504,32 @@ def test_config1_vs_oracle():
     vq.forced_indices = None
 
 
+def test_config1_training_trajectory_follows_the_oracle():
+    """Sixteen CTClipTrainer.train_step()s on config 1 (its two batches in turn) at a learning rate 40x the default, against the
+    f32 oracle trained the same way (forward, clip at 0.5, Adam, EMA codebook): the loss must FALL, and the two trajectories
+    must stay together -- an end-to-end check of backward + fused clip / Adam + codebook update over many steps, where a wrong
+    sign, a stale shadow weight or a lost moment shows as drift.  Free-running nearest-code decisions (bf16 near-ties flip,
+    see test_config1_vs_oracle) and 16 steps of Adam bound how tight this can be; the bars are 3x what was observed."""
+    from utils.CTClipTrainer import CTClipTrainer
+    from oracle import ctclip_oracle as O
+    clip, data, cfg = _config1()
+    st0 = {k: v.clone() for k, v in clip.state_dict().items()}
+    frozen = [k for k in st0 if k.endswith(".beta") or "vq._codebook." in k or not st0[k].is_floating_point()]
+    steps, lr = 16, 5e-4
+    batches = [data[s % 2] for s in range(steps)]
+    ref_losses, _, _ = O.train_steps(st0, batches, cfg, lr=lr, max_grad_norm=0.5, frozen=frozen)
+    trainer = CTClipTrainer(clip, batch_size=4, lr=lr, results_folder=None)
+    losses = [trainer.train_step((vol, txt)) for txt, vol in batches]
+    worst = max(abs(a - b) / abs(b) for a, b in zip(losses, ref_losses))
+    print("  hip   : " + " ".join(f"{x:.4f}" for x in losses))
+    print("  oracle: " + " ".join(f"{x:.4f}" for x in ref_losses))
+    print(f"  worst relative distance over {steps} steps: {worst:.3e}; last-four mean {sum(losses[-4:]) / 4:.4f} vs first-two {sum(losses[:2]) / 2:.4f}")
+    assert all(math.isfinite(x) for x in losses)
+    assert sum(losses[-4:]) / 4 < 0.8 * sum(losses[:2]) / 2, "the loss does not fall"
+    assert sum(ref_losses[-4:]) / 4 < 0.8 * sum(ref_losses[:2]) / 2, "the oracle's loss does not fall: test set-up"
+    assert worst <= 0.12, "HIP and oracle training trajectories drift apart"       # observed 3.6e-2 (step 1: 1.4961 vs 1.4474)
+
+
 def test_config1_two_training_steps():
     """Two full CTClipTrainer.train_step()s on config 1 (EMA codebook update, clip, fused Adam): finite, and the step-0
     loss agrees with the oracle's training-mode step within the free-running bound."""
