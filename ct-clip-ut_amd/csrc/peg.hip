@@ -10,9 +10,6 @@
 // dsconv.weight[d,1,3,3,3]) so that a wave reads one coalesced row per tap.
 #include "common.h"
 #include <stdlib.h>
-#ifndef PEG_LATE_STORE
-#define PEG_LATE_STORE 0            // A/B: half of the waves store a plane's rows at the top of the next step
-#endif
 #ifndef PEG_STAMPS
 #define PEG_STAMPS 0                // diagnostic build: per-wave cycle totals of the plane sweep's phases (tools/bench_peg.py STAMPS=1)
 #endif
@@ -265,12 +262,6 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
     }
   };
 
-#if PEG_LATE_STORE
-  // The two waves of a SIMD (w and w + 4) store at different ends of the plane step: the early half right after its FMAs, the
-  // late half at the top of the NEXT step -- so one half's stores (the CU's ~16 B per clock store path) run under the other
-  // half's LDS reads and FMAs instead of all eight waves storing, then all eight computing.
-  const bool late = ((tid >> 6) & 4) != 0;
-#endif
   load_plane(0, nx);
   __syncthreads();                                           // zero fill + weights visible
   // the bias row came from a global load: the barrier above has waited for it, but inside the loop the compiler's wait-count
@@ -294,14 +285,6 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
     long long c_last = __builtin_readcyclecounter();
 #endif
     const int buf = tp & 1;
-#if PEG_LATE_STORE
-    if (late && tp > 0) {                                    // the previous plane's finished rows: stored while the other half computes
-      const int tprev = FWD ? tp - 1 : tp - 3;
-      if (tprev >= 0) store_row(tprev, acc[0]);
-#pragma unroll
-      for (int i = 0; i < PL_P; ++i) { acc[0][i] = acc[1][i]; acc[1][i] = acc[2][i]; acc[2][i] = zero; }
-    }
-#endif
     if (tp + 2 < g.T) load_plane(tp + 2, nx2);               // in flight while this plane and the next are consumed
     PEG_ST(0)
     const f32x4* pb = plane + buf * plane_f4;
@@ -339,16 +322,11 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
       }
     }
     PEG_ST(1)
-#if PEG_LATE_STORE
-    if (!late)
-#endif
-    {
-      const int tout = FWD ? tp : tp - 2;
-      if (tout >= 0) store_row(tout, acc[0]);
-      PEG_ST(2)
+    const int tout = FWD ? tp : tp - 2;
+    if (tout >= 0) store_row(tout, acc[0]);
+    PEG_ST(2)
 #pragma unroll
-      for (int i = 0; i < PL_P; ++i) { acc[0][i] = acc[1][i]; acc[1][i] = acc[2][i]; acc[2][i] = zero; }
-    }
+    for (int i = 0; i < PL_P; ++i) { acc[0][i] = acc[1][i]; acc[1][i] = acc[2][i]; acc[2][i] = zero; }
     if (tp + 1 < g.T) stage_plane(buf ^ 1);
 #pragma unroll
     for (int i = 0; i < PL_P; ++i) nx[i] = nx2[i];
@@ -356,14 +334,6 @@ __global__ __launch_bounds__(PL_MAXT) void peg_plane_kernel(const float* __restr
     lds_only_barrier();
     PEG_ST(4)
   }
-#if PEG_LATE_STORE
-  if (late) {                                                // the last plane's rows and the rotation it still owes
-    const int tprev = FWD ? g.T - 1 : g.T - 3;
-    if (tprev >= 0) store_row(tprev, acc[0]);
-#pragma unroll
-    for (int i = 0; i < PL_P; ++i) { acc[0][i] = acc[1][i]; acc[1][i] = acc[2][i]; acc[2][i] = zero; }
-  }
-#endif
   if (!FWD) {
     if (g.T >= 2) store_row(g.T - 2, acc[0]);
     store_row(g.T - 1, acc[1]);
