@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """CT-CLIP contrastive training-step benchmark (BASELINE.json metric: CT-volume-report pairs/s, 480x480x240 bf16).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # N > 1 from a plain shell starts its own N ranks (self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
@@ -420,12 +420,47 @@ def cpu_config1(O, reps, log):
             "sample": f"two full training steps x {reps} repetitions after one warm-up, 4 pairs per step", "loss": losses[-1]}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a plain shell (no RANK / WORLD_SIZE): start the N ranks the way the reference gets them
+    from `accelerate launch` (src/utils/CTClipTrainer.py:62-69) -- one process per GPU through torch.distributed.run on
+    127.0.0.1 -- relay rank 0's JSON line (the children inherit this stdout) and return their exit code.  This parent never
+    touches HIP: it only counts devices (which does not initialise the runtime on this image) and waits."""
+    import socket
+    import subprocess
+    backend = os.environ.get("CTCLIP_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print(f"bench.py: --gpus {n} but {have} device(s) visible (RCCL needs one device per rank; "
+              "CTCLIP_DIST_BACKEND=gloo rehearses several ranks on one)", file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool: RCCL needs it
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] self-launch: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous():
+    """Ranks started by torch.distributed.run (or by self_launch): bring the process group up BEFORE the model is built, so a
+    launch problem shows in seconds; CTClipTrainer's runtime then finds it initialised."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or dist.is_initialized():
+        return
+    from datetime import timedelta
+    backend = os.environ.get("CTCLIP_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()))
+    dist.init_process_group(backend=backend, timeout=timedelta(seconds=36000))
+    print(f"[bench] rank {dist.get_rank()} of {dist.get_world_size()}: process group up ({backend})", file=sys.stderr, flush=True)
+
+
 def main():
-    # stdout carries exactly ONE line, the JSON: libraries that print to file descriptor 1 (RCCL's version banner at the first
-    # collective, gloo's connection messages) are sent to stderr for the whole run and the line goes to the real stdout
-    real_stdout = os.fdopen(os.dup(1), "w")
-    sys.stdout.flush()
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -441,6 +476,14 @@ def main():
     ap.add_argument("--local-negatives", action="store_true", help="BASELINE config 3: no embedding all-gather")
     ap.add_argument("--small", action="store_true", help="debug: 2+2-layer model on 64^3 volumes")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    # stdout carries exactly ONE line, the JSON: libraries that print to file descriptor 1 (RCCL's version banner at the first
+    # collective, gloo's connection messages) are sent to stderr for the whole run and the line goes to the real stdout
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    rendezvous()
 
     from utils.CTClipTrainer import CTClipTrainer
     from ctclip_hip.lib import hip
@@ -457,7 +500,7 @@ def main():
     rt = trainer.accelerator
     world, rank, dev = rt.num_processes, rt.process_index, rt.device
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus disagree")
     vol, txt = synthetic_batch(args.batch, depth, size, args.text_len, text_cfg["vocab_size"], dev, rank)
     batch = (vol, txt)
 

@@ -4,6 +4,7 @@ of SURVEY.md 8(e): after averaging, encoder gradients equal (1/W) * d(global los
 un-scaled gradient.  No HIP kernels run here; compute pieces are stood in by plain torch expressions of the same math
 (the point is the collective wiring, which is identical on RCCL)."""
 import os
+import sys
 import socket
 
 import pytest
@@ -292,6 +293,30 @@ def _sharded_weak_scaling_units(rank):
 
 def test_bench_shards_units_and_takes_max_time():
     _run(_sharded_weak_scaling_units)
+
+
+def test_bench_self_launches_its_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment (how the driver starts the scaling run): the
+    parent starts two ranks through torch.distributed.run on 127.0.0.1, both rendezvous (gloo here) before anything touches a
+    device, and the parent returns the children's exit code -- non-zero in this GPU-less container, where the training step
+    refuses to run ("no HIP device visible": there is no CPU fallback).  On a GPU box the same command prints the JSON line
+    (profiles/r04_self_launch_two_ranks.json)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CTCLIP_DIST_BACKEND"] = "gloo"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--small", "--steps", "1", "--warmup", "0",
+                        "--batch", "2", "--lean"], env=env, capture_output=True, text=True, timeout=600)
+    err = r.stderr
+    assert "[bench] self-launch:" in err and "--nproc-per-node=2" in err, err[-2000:]
+    assert "rank 0 of 2: process group up (gloo)" in err and "rank 1 of 2: process group up (gloo)" in err, err[-2000:]
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "no HIP device visible" in err, err[-2000:]
+        assert r.stdout.strip() == ""
+    else:
+        import json
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert r.returncode == 0 and line["n_gpus"] == 2
 
 
 # ---------------------------------------------------------------------------------------------------------------------
