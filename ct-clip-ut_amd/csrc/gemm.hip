@@ -428,6 +428,9 @@ int ctclip_gemm3_launch(const void* A, const void* B, void* C, const float* bias
 int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                            long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                            int hm_n, int hm_heads, hipStream_t st);
+int ctclip_gemm5_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
+                        long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
+                        int hm_n, int hm_heads, hipStream_t st);
 int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
                         float alpha, float* part, hipStream_t st);
 int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
@@ -435,6 +438,36 @@ int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* p
 extern "C" int ctclip_geglu_fwd(const void* h, void* g, long rows, int inner, int block, long ldh, long ldg, void* stream);
 extern "C" int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long rows, int inner, int block, long lddg, long ldh,
                                 void* stream);
+
+namespace {
+// gemm5.hip (one wave per SIMD, 128 x 128 per wave, paired full-line LDS-DMA) takes the k-major x k-major products on which it
+// measured faster than gemm3.hip's 8 x (128 x 64) tile (profiles/r04_gemm5.txt, interleaved on one box, 32 pairs): FF1 + GEGLU
+// (1831 vs 1931 us) and plain products with many column tiles (N >= 2048: FF1 forward 885 vs 830 TFLOP/s); gemm3 stays on
+// the N <= 1408 shapes (kv forward 765 vs 788, out-projection 508 vs 534) and on FF2 dgrad + GEGLU backward (1548 vs 1462 us).
+// K % 64 == 0 and K >= 192 (six K-steps: the ring fill).  Under the test hook CTCLIP_GEMM_V2_ALL every eligible product with
+// K >= 1024 goes to gemm5 so that the suite reaches all of its epilogues with small shapes (products with K < 1024 keep
+// exercising gemm3); CTCLIP_GEMM5_MINK (-DCTCLIP_TUNING_KNOBS builds: A/B runs) makes K >= that value the only criterion.
+bool gemm5_takes(int N, int K, int act) {
+  static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
+  static const int mink = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM5_MINK"); return e ? atoi(e) : -1; }();
+  if ((K % 64) != 0 || K < 192) return false;
+  if (mink >= 0) return K >= mink;
+  if (v2_all) return K >= 1024;
+  return act == 2 || (act <= 1 && N >= 2048);
+}
+// every k-major x k-major launch of the 256 x 256 LDS-DMA kernels goes through here: gemm5 when it takes the shape and the
+// output allows the 16-byte register epilogue (it returns hipErrorInvalidValue otherwise, before launching anything)
+int launch_kk(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K, long lda,
+              long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg, int hm_n, int hm_heads,
+              hipStream_t st) {
+  if (gemm5_takes(N, K, act)) {
+    const int e = ctclip_gemm5_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, G, ldg, hm_n,
+                                      hm_heads, st);
+    if (e != (int)hipErrorInvalidValue) return e;
+  }
+  return ctclip_gemm3_launch_hm(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, G, ldg, hm_n, hm_heads, st);
+}
+}  // namespace
 
 extern "C" {
 
@@ -478,8 +511,8 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
     const long blocks3 = (long)((M + 255) / 256) * ((N + 255) / 256);
     if (!no_v3 && !force_v1 && a_kmajor && b_kmajor && (K % 32) == 0 && split_k <= 1 && !accumulate &&
         (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
-      return ctclip_gemm3_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, nullptr, 0,
-                                 (hipStream_t)stream);
+      return launch_kk(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, nullptr, 0, 0, 0,
+                       (hipStream_t)stream);
     // weight gradients (m-major x n-major, split over the tokens) with enough 256 x 256 x split workgroups go to gemm4.hip,
     // the transposed-operand form of the same tile.  CTCLIP_GEMM_NO_V4=1 disables it.
     static const bool no_v4 = CTCLIP_KNOB("CTCLIP_GEMM_NO_V4") != nullptr;
@@ -525,8 +558,8 @@ int ctclip_gemm_bf16_headmajor(const void* A, const void* B, void* C, int M, int
                                int heads, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true) || (K % 32) || n_tokens <= 0) return (int)hipErrorInvalidValue;
-  return ctclip_gemm3_launch_hm(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, N, 0, 0, 1.0f, 0, nullptr, 0, n_tokens, heads,
-                                (hipStream_t)stream);
+  return launch_kk(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, N, 0, 0, 1.0f, 0, nullptr, 0, n_tokens, heads,
+                   (hipStream_t)stream);
 }
 
 // scores[m][n] = sum_k A[m][k] B[n][k], never materialised; for every column n writes 16 candidates: the top-4 of each
@@ -582,7 +615,7 @@ int ctclip_gemm_bf16_geglu(const void* A, const void* Bw, void* H, void* G, int 
   const long blocks3 = (long)((M + 255) / 256) * ((N + 255) / 256);
   const bool aligned = (ldh & 7) == 0 && (ldg & 7) == 0 && ((((uintptr_t)H) | ((uintptr_t)G)) & 15) == 0;
   if (!no_v3 && aligned && (K % 32) == 0 && (N % 256) == 0 && (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
-    return ctclip_gemm3_launch(A, Bw, H, nullptr, nullptr, M, N, K, lda, ldb, ldh, 0, 0, 1.0f, 2, G, ldg, (hipStream_t)stream);
+    return launch_kk(A, Bw, H, nullptr, nullptr, M, N, K, lda, ldb, ldh, 0, 0, 1.0f, 2, G, ldg, 0, 0, (hipStream_t)stream);
   // small problems: the plain product, then the gated activation over the same interleaved layout
   if (int e = ctclip_gemm_bf16(A, Bw, H, nullptr, nullptr, M, N, K, lda, ldb, ldh, 0, 1, 1, 0, 1, 0, 1.0f, 0, nullptr, 0, stream)) return e;
   return ctclip_geglu_fwd(H, G, M, inner, 32, ldh, ldg, stream);
@@ -597,8 +630,8 @@ int ctclip_gemm_bf16_geglu_bwd(const void* dY, const void* W2T, void* H_dH, void
   const long blocks3 = (long)((M + 255) / 256) * ((inner + 255) / 256);
   const bool aligned = (ldh & 7) == 0 && (((uintptr_t)H_dH) & 15) == 0;
   if (!no_v3 && aligned && (K % 32) == 0 && (blocks3 >= 192 || (v2_all && blocks3 >= 4)))
-    return ctclip_gemm3_launch(dY, W2T, nullptr, nullptr, nullptr, M, inner, K, lddy, ldw, 0, 0, 0, 1.0f, 3, H_dH, ldh,
-                               (hipStream_t)stream);
+    return launch_kk(dY, W2T, nullptr, nullptr, nullptr, M, inner, K, lddy, ldw, 0, 0, 0, 1.0f, 3, H_dH, ldh, 0, 0,
+                     (hipStream_t)stream);
   // small problems: dg into the scratch, then the blocked GEGLU backward in place over h
   if (!dG_scratch) return (int)hipErrorInvalidValue;
   if (int e = ctclip_gemm_bf16(dY, W2T, dG_scratch, nullptr, nullptr, M, inner, K, lddy, ldw, lddg, 0, 1, 1, 0, 1, 0, 1.0f, 0, nullptr, 0, stream))

@@ -1,0 +1,313 @@
+// bf16 MFMA GEMM, 256 x 256 tile, ONE WAVE PER SIMD: 4 waves x (128 x 128) -- the k-major x k-major products of the CT-CLIP
+// step with a long K (FF2 forward K = 1408, FF1 data gradient K = 2816, the tubelet projection K = 4000; every nn.Linear of
+// src/utils/attention.py:38-51,118-124 goes through ctclip_gemm_bf16, which picks this kernel or gemm3.hip by shape).
+//
+// Why a second tile shape.  gemm3.hip runs 8 waves x (128 x 64): per 32-deep K-step a wave reads 12 fragments for 32 MFMAs and
+// the two waves of a SIMD alternate between a load block and an MFMA block; its K-step takes ~1600 cycles against 1024 of
+// matrix work (profiles/r03_gemm_timeline.txt).  The vendor library's fastest kernels on these shapes
+// (profiles/r04_gemm_vs_vendor.txt: MT256x256x64, 256 threads, 130 KiB of LDS, 256 + 256 registers) are one wave per SIMD with a
+// 128 x 128 wave tile: 16 fragment reads per 64 MFMAs -- half the LDS traffic per flop -- and nobody to share the matrix pipe
+// with.  This kernel is that design on this repo's ring:
+//   * 256 accumulator registers per lane (8 x 8 MFMA 16x16x32 tiles), fragments DOUBLE-BUFFERED in registers (2 x 64): the
+//     16 ds_read_b128 of K-step j + 1 and the wave's 8 LDS-DMA issues of K-step j + NS are spread between the 64 MFMAs of
+//     K-step j, one (2 reads + 1 DMA) group per 8 MFMAs, so the matrix pipe always has work queued behind a memory instruction;
+//   * the same k32 LDS tiles, source-side swizzle and permuted N-fragment rows as gemm3.hip (gemm_tile.h), NS slots of 32 KiB
+//     filled by global_load_lds with counted vmcnt; ONE barrier per K-step (after the next K-step's fragments are in
+//     registers its slot is free again);
+//   * persistent over tiles, the next tile's ring fill requested before the epilogue's stores, as gemm3.hip;
+//   * the register epilogue of gemm_tile.h, once per 64-column slab of the wave's 128 columns.
+// Preconditions (dispatcher in gemm.hip): both operands k-major, K % 32 == 0, no split-K / accumulate.
+#include "gemm_tile.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace g5 {
+using namespace g3;
+
+#ifndef G5_PAIR
+#define G5_PAIR 1         // 1: the two k32 halves of the same 128-byte lines are requested back to back (even K-steps issue 16
+#endif                    //    pieces, odd ones none; five slots); 0: one K-step's 8 pieces per step (four slots)
+#ifndef G5_NS
+#define G5_NS (G5_PAIR ? 5 : 4)
+#endif
+
+#ifndef G5_ABL
+#define G5_ABL 0          // timing-only ablations of the K-step (diagnostic builds; results are wrong): 1 no DMA issue, 2 no fragment
+#endif                    // reads, 4 no barrier, 8 no issue-side bookkeeping
+
+#ifdef CTCLIP_G5_PROF
+// diagnostic build only (hipcc -DCTCLIP_G5_PROF, tools/gemm5_prof.py): per wave, shader-cycle sums of the K-step's segments
+// {MFMA + issue block, vmcnt wait, lgkmcnt wait, barrier}, the epilogue, the K-step count and the wave's whole life
+__device__ unsigned long long* g5_prof = nullptr;      // [blocks][4 waves][8]
+#define G5_SEG_DECL() unsigned long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long c_ = __builtin_amdgcn_s_memtime(); const unsigned long long c0_ = c_
+#define G5_SEG(n) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); seg_[n] += t_ - c_; c_ = t_; } while (0)
+#define G5_CNT(n) do { seg_[n] += 1; } while (0)
+#define G5_SEG_STORE()                                                                                            \
+  do {                                                                                                            \
+    seg_[7] = __builtin_amdgcn_s_memtime() - c0_;                                                                 \
+    if (g5_prof && lane == 0)                                                                                     \
+      for (int n_ = 0; n_ < 8; ++n_) g5_prof[((long)blockIdx.x * 4 + wave) * 8 + n_] = seg_[n_];                  \
+  } while (0)
+#else
+#define G5_SEG_DECL() do { } while (0)
+#define G5_SEG(n) do { } while (0)
+#define G5_CNT(n) do { } while (0)
+#define G5_SEG_STORE() do { } while (0)
+#endif
+
+// The accumulators are pinned to the AccVGPR half of the register file by issuing the MFMAs from inline asm ("+a"): left to
+// the register allocator, the 256 accumulator + 128 fragment registers of this kernel end in copies between the two halves
+// and ~700 spilled dwords.  Hazards the compiler no longer sees: an MFMA that accumulates into the registers the previous
+// MFMA wrote needs no wait states when the registers are exactly the same (they are); the epilogue's first v_accvgpr_read
+// is kept 18+ wait states behind the last MFMA by the barrier and the s_nops in front of it.
+__device__ __forceinline__ void mfma_acc(f32x4& c, bf16x8 a, bf16x8 b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_zero(f32x4& c, bf16x8 a, bf16x8 b) {      // first K-step of a tile: C = 0
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+}
+
+template <int EPI, int NS>
+__global__ __launch_bounds__(256) void gemm5_kernel(Args g) {
+  constexpr bool F32OUT = EPI == 1;
+  constexpr int IM = 8, JN = 8, BN = 256;
+  constexpr int STAGE = 2 * SUB;                     // a slot: the A tile (256 x 32 bf16) and the B tile behind it, 32 KiB
+  constexpr int PPW = STAGE / 1024 / 4;              // 1 KiB DMA pieces per wave and slot: 8
+  constexpr int NST = 2 * IM * (EPI == 0 ? 2 : EPI == 2 ? 3 : 4);   // 16-byte stores per wave of a full tile's register epilogue
+  constexpr bool PAIR = G5_PAIR != 0;
+  static_assert(!PAIR || NS == 5, "paired issue needs five slots");
+  // pieces that may stay in flight when K-step j + 2 must have landed.  Plain: K-steps j + 3 .. j + NS.  Paired (K-steps 2P + 4,
+  // 2P + 5 are issued during step 2P): after an even step j + 3, j + 4, j + 5, after an odd one j + 3, j + 4
+  constexpr int C_DMA = PAIR ? 3 * PPW : (NS - 2) * PPW;
+  constexpr int C_ODD = PAIR ? 2 * PPW : C_DMA;
+  constexpr int C_ST = C_DMA + NST > 63 ? 63 : C_DMA + NST;   // ... and an epilogue's stores behind them (vmcnt holds 6 bits)
+  constexpr int C_ODD_ST = C_ODD + NST > 63 ? 63 : C_ODD + NST;
+  constexpr int NPRO = PAIR ? 4 : NS;                // K-steps of the ring fill
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+
+  const int total = g.tiles_m * g.tiles_n;
+  if ((int)blockIdx.x >= total) return;
+  const int nk = g.K / BK;                           // even, >= NS (dispatcher)
+
+  // ---- issue side: the (tile, K-step) sequence of this workgroup is FLATTENED, the ring never drains between tiles.
+  // Piece q = wave * PPW + j of a slot: the first 16 are the A tile (waves 0, 1), the rest the B tile (waves 2, 3), so a wave
+  // streams ONE operand: a uniform 64-bit base (tile row 0 + the K-step's offset, SGPRs) and a 32-bit byte offset per piece
+  // and lane (rows clamped to the operand's last row: masked in the epilogue).  LDS destination of piece j: slot + dst0 + j KiB.
+  const bool isA = wave < 2;
+  const bf16_t* const opnd = isA ? g.A : g.B;
+  const long ld = isA ? g.lda : g.ldb;
+  const int R = isA ? g.M : g.N;
+  const uint32_t dst0 = (uint32_t)(wave * PPW * 1024);
+  const char* ibase;                                 // operand at (issue tile row 0, issue K-step)
+  // byte offset of piece i for this lane = min(voff0 + i * rowstep, vlast): sixteen rows further per piece, clamped to the
+  // operand's last row (two registers instead of one per piece: every register of this kernel is spoken for)
+  uint32_t voff0, vlast;
+  const uint32_t rowstep = (uint32_t)(16 * ld * 2);
+  uint32_t half1 = 64;                               // the second k32 half of a line (paired form), kept in a register: an immediate
+  asm volatile("" : "+s"(half1));                    // offset of a global_load_lds is added to the LDS address as well
+  int itile = blockIdx.x, ik = 0, islot = 0;
+  auto locate_issue = [&](int t) {
+    const int bid = xcd_remap(t, total);
+    const int r0 = isA ? (bid / g.tiles_n) * BM : (bid % g.tiles_n) * BN;
+    ibase = (const char*)(opnd + (long)r0 * ld);
+    const int r = 16 * ((wave & 1) * PPW) + (lane >> 2), c = (lane & 3) ^ swz_key(r);     // the key is the same for every piece
+    voff0 = (uint32_t)((long)r * ld * 2 + c * 16);
+    vlast = (uint32_t)((long)(R - 1 - r0) * ld * 2 + c * 16);
+  };
+  // after the wave's PPW pieces of a K-step have been issued: next K-step, next tile of this workgroup; past the last tile the
+  // last K-step is issued again (into a slot nobody reads any more), which keeps the loop body and the wait counts uniform
+  auto advance_issue = [&]() {                       // (paired form: by two K-steps; nk is even)
+    constexpr int D = PAIR ? 2 : 1;
+    islot = islot + D >= NS ? islot + D - NS : islot + D;
+    if ((ik += D) < nk) { ibase += D * BK * 2; return; }
+    const int nt = itile + (int)gridDim.x;
+    if (nt < total) { itile = nt; ik = 0; locate_issue(nt); }
+    else ik = nk - D;
+  };
+  // piece i of the K-step(s) at the issue position: plain -> slot islot; paired -> the k32 half at ibase into slot islot and the
+  // other half of the same lines (64 bytes further) into the next slot, back to back, so that the second request finds the
+  // line in the L1 or already on its way
+  auto issue_piece = [&](int i) {
+    const uint32_t d0 = lds0 + (uint32_t)(islot * STAGE) + dst0 + i * 1024;
+    const uint32_t v = min(voff0 + (uint32_t)i * rowstep, vlast);
+    G3_GLDS(ibase + v, d0);
+    if constexpr (PAIR) {
+      const int s1 = islot + 1 == NS ? 0 : islot + 1;
+      G3_GLDS(ibase + (v + half1), lds0 + (uint32_t)(s1 * STAGE) + dst0 + i * 1024);
+    }
+  };
+  locate_issue(itile);
+#pragma unroll
+  for (int t = 0; t < NPRO; t += (PAIR ? 2 : 1)) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) issue_piece(j);
+    advance_issue();
+  }
+
+  // ---- consume side.  Fragment addresses inside a slot: M rows 16 i + ml of this wave's 128 rows; (permuted) N rows of its
+  // two 64-column slabs.  N-fragment j = 4 s + jj (slab s, fragment jj): slab rows 16 jj + ml (f32 outputs) or nfrag_row(jj, ml)
+  // (bf16): 64 rows (a slab) or 32 rows (jj + 2) further is a constant 4096 / 2048 bytes; jj + 1 changes the swizzle key of the
+  // permuted form
+  const int ml = lane & 15, q4 = lane >> 4;
+  const uint32_t offA = tile_off(wm * 128 + ml, q4);          // + i * 1024: sixteen rows further, same swizzle key
+  const uint32_t offB0 = SUB + tile_off(wn * 128 + (F32OUT ? ml : nfrag_row(0, ml)), q4);
+  const uint32_t offB1 = SUB + tile_off(wn * 128 + (F32OUT ? 16 + ml : nfrag_row(1, ml)), q4);
+  auto offB = [&](int j) { return ((j & 1) ? offB1 : offB0) + (uint32_t)(4096 * (j >> 2) + 2048 * ((j >> 1) & 1)); };
+
+  G5_SEG_DECL();
+  f32x4 acc[IM][JN];
+  // the row fragments ROTATE (fa[i] is re-loaded with the next K-step's rows as soon as its eight MFMAs have been issued: no
+  // second copy), the column fragments are double-buffered: 96 fragment registers, which leaves the allocator the slack that
+  // keeps the loop free of spills (a scratch reload waits with vmcnt(0) and would drain the ring)
+  bf16x8 fa[IM], fb[2][JN];
+  int cslot = 0;                                     // slot of the K-step whose fragments are in registers
+  int post = 0;                                      // K-steps after an epilogue whose wait leaves its stores in flight
+
+#define G5_BAR()                                                                       \
+  do {                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    __builtin_amdgcn_s_barrier();                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+  } while (0)
+  // One K-step: 64 MFMAs on (fac, fbc); the 16 fragment reads of the next K-step (slot cslot + 1) and this wave's 8 DMA issues
+  // of K-step + NS (into slot cslot, whose fragments are the ones in registers) go out between the row groups.  The last
+  // reads are issued one row group early so that their latency is covered.  ZERO: first K-step of a tile (C = 0).
+  auto step = [&](auto zero_t, auto odd_t, bf16x8 (&fbc)[JN], bf16x8 (&fbn)[JN]) {
+    constexpr bool ZERO = decltype(zero_t)::value, ODD = decltype(odd_t)::value;
+    const int nslot = cslot + 1 == NS ? 0 : cslot + 1;
+    const char* st = smem + nslot * STAGE;
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+#pragma unroll
+      for (int jj = 0; jj < JN; ++jj) {                                  // transposed: see nfrag_row()
+        if constexpr (ZERO) mfma_zero(acc[i][jj], fbc[jj], fa[i]);
+        else mfma_acc(acc[i][jj], fbc[jj], fa[i]);
+      }
+      if (!(G5_ABL & 2)) {
+      fa[i] = *(const bf16x8*)(st + offA + i * 1024);
+      if (i < IM - 1) fbn[i] = *(const bf16x8*)(st + offB(i));
+      if (i == IM - 2) fbn[JN - 1] = *(const bf16x8*)(st + offB(JN - 1));
+      }
+      if (!(G5_ABL & 1) && !(PAIR && ODD)) issue_piece(i);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!(G5_ABL & 8) && !(PAIR && ODD)) advance_issue();
+    cslot = nslot;
+    G5_SEG(0); G5_CNT(5);
+    // own pieces of the K-step after the next landed (it is read during the next step, behind this barrier)
+    if (post > 0) { if (ODD) wait_vm<C_ODD_ST>(); else wait_vm<C_ST>(); --post; }
+    else { if (ODD) wait_vm<C_ODD>(); else wait_vm<C_DMA>(); }
+    G5_SEG(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of slot `nslot` retired before the barrier that frees it
+    G5_SEG(2);
+    if (!(G5_ABL & 4)) G5_BAR();
+    G5_SEG(3);
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
+  // K-steps 0 and 1 landed for everybody; fragments of K-step 0; its slot is free
+  wait_vm<(NPRO - 2) * PPW>();
+  G5_BAR();
+#pragma unroll
+  for (int i = 0; i < IM; ++i) fa[i] = *(const bf16x8*)(smem + offA + i * 1024);
+#pragma unroll
+  for (int j = 0; j < JN; ++j) fb[0][j] = *(const bf16x8*)(smem + offB(j));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  G5_BAR();
+
+  for (int tile = blockIdx.x; tile < total; tile += (int)gridDim.x) {
+    step(T_{}, F_{}, fb[0], fb[1]);
+    step(F_{}, T_{}, fb[1], fb[0]);
+    for (int k = 2; k < nk; k += 2) {
+      step(F_{}, F_{}, fb[0], fb[1]);
+      step(F_{}, T_{}, fb[1], fb[0]);
+    }
+    const int bid = xcd_remap(tile, total);
+    const int erow0 = (bid / g.tiles_n) * BM, ecol0 = (bid % g.tiles_n) * BN;
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // MFMA results -> v_accvgpr_read (see mfma_acc)
+    const int rbase = erow0 + wm * 128, colw = ecol0 + wn * 128;
+    // the lane id afresh (mbcnt), not the register live since the kernel's entry: keeps the epilogue's per-lane addresses from
+    // being hoisted out of the tile loop, where they would stay live across the matrix loop (every register there is spoken for)
+    int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane_e));
+    epilogue_slab<EPI, IM, JN, 0, true, false>(g, acc, rbase, colw, lane_e);
+    epilogue_slab<EPI, IM, JN, 4, true, false>(g, acc, rbase, colw + 64, lane_e);
+    if (g.direct && erow0 + BM <= g.M && ecol0 + BN <= g.N) post = 2;     // the next two steps wait for pieces older than the stores
+    else wait_vm<0>();                                  // ragged tile: its store count is not the constant NST
+    G5_SEG(4);
+  }
+  G5_SEG_STORE();
+  wait_vm<0>();                                         // no LDS-DMA may be in flight when the workgroup's LDS is released
+#undef G5_BAR
+}
+
+}  // namespace g5
+
+// called by the dispatcher in gemm.hip: same contract as ctclip_gemm3_launch_hm
+int ctclip_gemm5_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
+                        long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
+                        int hm_n, int hm_heads, hipStream_t st) {
+  using namespace g5;
+  if (hm_n > 0 && (c_fp32 || act != 0 || hm_heads <= 0 || (M % hm_n) || (N & 63) || (N / 32) % hm_heads || (((uintptr_t)C) & 15) ||
+                   hm_n < 2 || (long)M * hm_n >= (1L << 32)))
+    return (int)hipErrorInvalidValue;
+  if (act < 0 || act > 3) return (int)hipErrorInvalidValue;
+  if (act == 2 && (c_fp32 || bias || resid || !G || (N & 63) || (ldc & 7) || (ldg & 7) || (((uintptr_t)C) & 15) ||
+                   (((uintptr_t)G) & 15)))
+    return (int)hipErrorInvalidValue;
+  if (act == 3 && (c_fp32 || bias || resid || !G || (N & 31) || (ldg & 7) || (((uintptr_t)G) & 15)))
+    return (int)hipErrorInvalidValue;
+  if ((K % (2 * BK)) || K / BK < 6) return (int)hipErrorInvalidValue;
+  Args g{};
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
+  g.act = act; g.alpha = alpha; g.G = (bf16_t*)G; g.ldg = ldg;
+  g.direct = (act >= 2) ||
+             ((N & 7) == 0 && (((uintptr_t)C) & 15) == 0 && (ldc & (c_fp32 ? 3 : 7)) == 0 &&
+              (!bias || (((uintptr_t)bias) & 15) == 0) && (!resid || ((((uintptr_t)resid) & 15) == 0 && (ldr & 3) == 0)));
+  if (!g.direct) return (int)hipErrorInvalidValue;     // unaligned outputs stay on gemm3.hip (dispatcher)
+  if (hm_n > 0) {
+    g.hm_n = hm_n; g.hm_heads = hm_heads;
+    g.hm_magic = (uint32_t)(((1ull << 32) + (unsigned long long)hm_n - 1) / (unsigned long long)hm_n);
+    g.hm_part = (long)M * hm_heads * 32;
+  }
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + 255) / 256;
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? (n / 8) * 8 : 256;                 // a multiple of 8 keeps a workgroup's tiles on one XCD's run
+  }();
+  const long total = (long)g.tiles_m * g.tiles_n;
+  const int grid = (int)(total < cus ? total : cus);
+  constexpr size_t lds = (size_t)G5_NS * 2 * SUB;
+#define G5_LAUNCH(EPI_)                                                                                                   \
+  do {                                                                                                                    \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm5_kernel<EPI_, G5_NS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)lds);                                                                       \
+      if (e != hipSuccess) return (int)e;                                                                                 \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((gemm5_kernel<EPI_, G5_NS>), dim3(grid), dim3(256), lds, st, g);                                   \
+  } while (0)
+  const int epi = act >= 2 ? act : (c_fp32 ? 1 : 0);
+  if (epi == 0) G5_LAUNCH(0);
+  else if (epi == 1) G5_LAUNCH(1);
+  else if (epi == 2) G5_LAUNCH(2);
+  else G5_LAUNCH(3);
+#undef G5_LAUNCH
+  return (int)hipGetLastError();
+}
+
+#ifdef CTCLIP_G5_PROF
+extern "C" int ctclip_debug_gemm5_prof(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g5::g5_prof), &p, sizeof(p));
+}
+#endif

@@ -151,6 +151,59 @@ def test_linear_geglu_fused_and_blocked_backward(hip, M, inner, K):
     check("fused dgrad+geglu dgate", H2b[:, :, 1].reshape(M, inner), gate.grad, 2.5e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(20000, 1408, 1024),    # 474 tiles > CUs: several tiles per workgroup (flattened ring), ragged last row tile
+                                   (4096, 512, 1408),      # FF2 forward shape (K = 44 K-steps)
+                                   (1000, 264, 2816),      # ragged in both directions, N % 256 != 0 (FF1 data-gradient K)
+                                   (3072, 768, 1024)])     # all tiles interior
+def test_gemm_one_wave_per_simd_tile(hip, M, N, K):
+    """k-major x k-major products with K % 64 == 0 and K >= 1024 go to csrc/gemm5.hip (4 waves x 128 x 128, accumulators in
+    AccVGPRs, flattened (tile, K-step) ring): every epilogue form of gemm_tile.h against f32 torch math on the same bf16
+    operands -- f32 + bias + residual + alpha, bf16 + bias + erf-GELU, head-major bf16, FF1 + GEGLU, FF2 dgrad + GEGLU
+    backward (reference attention.py:38-51,118-124)."""
+    A, B = bf(rnd(M, K, seed=11) * 0.5), bf(rnd(N, K, seed=12) * 0.5)
+    ref = A.float() @ B.float().t()
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    C = torch.empty(M, N, device=DEV)
+    hip.gemm_bf16(A, B, C, bias, res, M, N, K, K, K, N, N, 1, 1, 1, 1, 0, 0.5, 0)
+    check(f"gemm5 f32 + bias + resid {M}x{N}x{K}", C, 0.5 * ref + bias + res, 2e-3)
+    C16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16(A, B, C16, bias, None, M, N, K, K, K, N, 0, 1, 1, 0, 1, 0, 1.0, 1)
+    check("gemm5 bf16 + bias + gelu", C16, torch.nn.functional.gelu(ref + bias), 1e-2)
+    wide = torch.zeros(M, N + 40, device=DEV, dtype=torch.bfloat16)                      # ldc > N: the columns beyond stay untouched
+    hip.gemm_bf16(A, B, wide, None, None, M, N, K, K, K, N + 40, 0, 1, 1, 0, 1, 0, 1.0, 0)
+    check("gemm5 bf16 ldc > N", wide[:, :N], ref, 1e-2)
+    assert float(wide[:, N:].float().abs().max()) == 0.0
+    if N % 64 == 0 and M % 8 == 0:
+        # head-major: [part][sequence][head][token][32]
+        n_tok = 8
+        heads = N // 32 // 2 if (N // 32) % 2 == 0 else N // 32
+        parts = N // (32 * heads)
+        hm = torch.empty(parts, M // n_tok, heads, n_tok, 32, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_bf16_headmajor(A, B, hm, M, N, K, K, K, n_tok, heads)
+        want = ref.view(M // n_tok, n_tok, parts, heads, 32).permute(2, 0, 3, 1, 4)
+        check("gemm5 head-major", hm, want, 1e-2)
+    if N % 128 == 0:
+        inner = N // 2                                                                    # B rows as interleaved [val 32 | gate 32] blocks
+        Hh = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        G = torch.empty(M, inner, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_bf16_geglu(A, B, Hh, G, M, inner, K, K, K, N, inner)
+        hb = ref.view(M, inner // 32, 2, 32)
+        check("gemm5 fused h", Hh, ref, 1e-2)
+        check("gemm5 fused g", G, (torch.nn.functional.gelu(hb[:, :, 1]) * hb[:, :, 0]).reshape(M, inner), 1.5e-2)
+        # dg = dY W2T^T with the GEGLU backward in place over h: here dY = A [M, K], W2T = B[:inner] ([inner, K])
+        h0 = bf(rnd(M, 2 * inner, seed=13))
+        h2 = h0.clone()
+        hip.gemm_bf16_geglu_bwd(A, B[:inner], h2, None, M, inner, K, K, K, 2 * inner, inner)
+        dg = bf(A.float() @ B[:inner].float().t()).float()
+        hv = h0.float().view(M, inner // 32, 2, 32)
+        val = hv[:, :, 0].reshape(M, inner).clone().requires_grad_(True)
+        gate = hv[:, :, 1].reshape(M, inner).clone().requires_grad_(True)
+        (torch.nn.functional.gelu(gate) * val).backward(dg)
+        got = h2.float().view(M, inner // 32, 2, 32)
+        check("gemm5 dgrad + geglu dval", got[:, :, 0].reshape(M, inner), val.grad, 2.5e-2)
+        check("gemm5 dgrad + geglu dgate", got[:, :, 1].reshape(M, inner), gate.grad, 2.5e-2)
+
+
 def test_gemm_mfma_orientation_asymmetric(hip):
     """A = I with an asymmetric B catches a transposed C write (guide: 'always A=I-check')."""
     n = 128
