@@ -45,12 +45,6 @@ __device__ long g_stamp_cap = 0;
 #define G3_SEG_STORE() do { } while (0)
 #endif
 
-#ifndef G3_SWP
-#define G3_SWP 0                        // 1: the software-pipelined main loop of gemm3_kernel (A/B builds: tools/build_variant.sh)
-#endif
-#ifndef G3_SWP_EARLY
-#define G3_SWP_EARLY 0
-#endif
 #ifndef G3_NS256
 #define G3_NS256 4
 #endif
@@ -150,8 +144,7 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
 #pragma unroll
   for (int j = 0; j < JN; ++j) offB[j] = SUB + tile_off(wn * 64 + (F32OUT ? 16 * j + ml : nfrag_row(j, ml)), q4);
 
-  constexpr bool SWP = G3_SWP && TBN == 256;          // three stages (TBN = 128) leave the pipelined loop no DMA lead
-  bf16x8 fa[IM], fb[JN], fb2[2][JN];
+  bf16x8 fa[IM], fb[JN];
   f32x4 acc[IM][JN];
   // own pieces of K-step k+1 landed; up to TNS - 2 younger K-steps (TPPW DMAs each) stay in flight
   auto wait_next = [&](int k) {
@@ -169,43 +162,6 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
     __builtin_amdgcn_s_barrier();                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                 \
   } while (0)
-  // SOFTWARE-PIPELINED main loop (one barrier per K-step, every wave the same program): the fragments of K-step k + 1 are
-  // read from LDS BETWEEN the MFMAs of K-step k -- the row fragment fa[i] is re-loaded as soon as its four MFMAs have been
-  // issued (register rotation: no second copy), only the four column fragments are double-buffered (+16 registers) -- and
-  // the wave's LDS-DMA issues of K-step k + NS - 1 sit between the MFMAs of the last row groups.  Both waves of a SIMD
-  // always have MFMAs to issue; a wave held up by an LDS read or a DMA issue leaves the pipe to its partner.
-  auto wait_next2 = [&](int k) {                    // own pieces of K-step k + 2 landed; K-steps k + 3 .. k + NS - 1 may stay in flight
-    if (k + 2 < nk) {
-      const int y = nk - 3 - k;                     // younger K-steps that exist
-      if (TNS >= 5 && y >= 2) wait_vm<2 * TPPW>();
-      else if (TNS >= 4 && y >= 1) wait_vm<TPPW>();
-      else wait_vm<0>();
-    }
-  };
-  auto swp_step = [&](int k, bf16x8 (&fbc)[JN], bf16x8 (&fbn)[JN]) {
-    const char* st = smem + ((k + 1) % TNS) * TSTAGE;
-    const bool more = k + 1 < nk, fill = k + TNS - 1 < nk;
-    const uint32_t sb = lds0 + (uint32_t)(((k + TNS - 1) % TNS) * TSTAGE);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < IM; ++i) {
-#pragma unroll
-      for (int j = 0; j < JN; ++j) acc[i][j] = mfma16(fbc[j], fa[i], acc[i][j]);
-      if (more) {
-        fa[i] = *(const bf16x8*)(st + offA + i * 1024);
-        if (i < JN) fbn[i] = *(const bf16x8*)(st + offB[i]);
-      }
-      if (fill && (G3_SWP_EARLY ? i < TPPW : i >= IM - TPPW)) {
-        const int j = G3_SWP_EARLY ? i : i - (IM - TPPW);
-        G3_GLDS(src[j] + (long)(k + TNS - 1) * BK, sb + dst[j]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    wait_next2(k);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of stage k + 1 retired before the barrier that frees it
-    G3_BAR();
-  };
   auto load_block = [&](int k) {
     const char* st = smem + (k % TNS) * TSTAGE;
 #pragma unroll
@@ -248,26 +204,6 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
   G3_BAR();
   G3_STAMP(3);
   G3_SEG_DECL();
-  if constexpr (SWP) {
-    const char* st0 = smem;                         // K-step 0 lives in stage 0
-#pragma unroll
-    for (int j = 0; j < JN; ++j) fb2[0][j] = *(const bf16x8*)(st0 + offB[j]);
-#pragma unroll
-    for (int i = 0; i < IM; ++i) fa[i] = *(const bf16x8*)(st0 + offA + i * 1024);
-    if (nk > 1) {                                   // own pieces of K-step 1 landed (the younger prologue K-steps and the stores may stay in flight)
-      constexpr int PRO = TNS - 3;                  // prologue K-steps younger than K-step 1
-      if (stores_pending) { if (nk > TNS - 2) wait_vm<NST + PRO * TPPW>(); else wait_vm<NST>(); }
-      else                { if (nk > TNS - 2) wait_vm<PRO * TPPW>(); else wait_vm<0>(); }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    G3_BAR();
-    int k = 0;
-    for (; k + 1 < nk; k += 2) {
-      swp_step(k, fb2[0], fb2[1]);
-      swp_step(k + 1, fb2[1], fb2[0]);
-    }
-    if (k < nk) swp_step(k, fb2[0], fb2[1]);
-  } else {
   // profiled segments: 0 load block issue, 1 lgkmcnt wait, 2 barrier after the load block, 3 MFMA block, 4 vmcnt wait,
   // 5 barrier after the MFMA block
   if (grp == 0) {
@@ -303,7 +239,6 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
       G3_BAR();
       G3_SEG(5);
     }
-  }
   }
   G3_SEG_STORE();
   G3_STAMP(4);

@@ -1,22 +1,25 @@
-// bf16 MFMA GEMM, 256 x 256 tile, ONE WAVE PER SIMD: 4 waves x (128 x 128) -- the k-major x k-major products of the CT-CLIP
-// step with a long K (FF2 forward K = 1408, FF1 data gradient K = 2816, the tubelet projection K = 4000; every nn.Linear of
-// src/utils/attention.py:38-51,118-124 goes through ctclip_gemm_bf16, which picks this kernel or gemm3.hip by shape).
+// bf16 MFMA GEMM, 256 x 256 tile, ONE WAVE PER SIMD: 4 waves x (128 x 128).  Takes the k-major x k-major products of the CT-CLIP
+// step on which it measured faster than gemm3.hip (dispatcher: csrc/gemm.hip, gemm5_takes): FF1 + GEGLU and plain products with
+// N >= 2048 (src/utils/attention.py:38-51; every nn.Linear of the path goes through ctclip_gemm_bf16).
 //
 // Why a second tile shape.  gemm3.hip runs 8 waves x (128 x 64): per 32-deep K-step a wave reads 12 fragments for 32 MFMAs and
-// the two waves of a SIMD alternate between a load block and an MFMA block; its K-step takes ~1600 cycles against 1024 of
-// matrix work (profiles/r03_gemm_timeline.txt).  The vendor library's fastest kernels on these shapes
-// (profiles/r04_gemm_vs_vendor.txt: MT256x256x64, 256 threads, 130 KiB of LDS, 256 + 256 registers) are one wave per SIMD with a
-// 128 x 128 wave tile: 16 fragment reads per 64 MFMAs -- half the LDS traffic per flop -- and nobody to share the matrix pipe
-// with.  This kernel is that design on this repo's ring:
-//   * 256 accumulator registers per lane (8 x 8 MFMA 16x16x32 tiles), fragments DOUBLE-BUFFERED in registers (2 x 64): the
-//     16 ds_read_b128 of K-step j + 1 and the wave's 8 LDS-DMA issues of K-step j + NS are spread between the 64 MFMAs of
-//     K-step j, one (2 reads + 1 DMA) group per 8 MFMAs, so the matrix pipe always has work queued behind a memory instruction;
-//   * the same k32 LDS tiles, source-side swizzle and permuted N-fragment rows as gemm3.hip (gemm_tile.h), NS slots of 32 KiB
-//     filled by global_load_lds with counted vmcnt; ONE barrier per K-step (after the next K-step's fragments are in
-//     registers its slot is free again);
-//   * persistent over tiles, the next tile's ring fill requested before the epilogue's stores, as gemm3.hip;
+// the two waves of a SIMD alternate between a load block and an MFMA block.  The vendor library's fastest kernels on the long-K
+// shapes (profiles/r04_gemm_vs_vendor.txt: MT256x256x64, 256 threads, 130 KiB of LDS, 256 + 256 registers) are one wave per SIMD
+// with a 128 x 128 wave tile: 16 fragment reads per 64 MFMAs -- half the LDS traffic per flop.  This kernel is that design on
+// this repo's ring (measurements: profiles/r04_gemm5.txt):
+//   * 256 accumulator registers per lane (8 x 8 MFMA 16x16x32 tiles) pinned to AccVGPRs; row fragments rotate, column
+//     fragments are double-buffered (96 registers): the 16 ds_read_b128 of K-step j + 1 go out between the 64 MFMAs of K-step j
+//     (one wave can hide them under its own MFMAs), ONE barrier per K-step;
+//   * the same k32 LDS tiles, source-side swizzle and permuted N-fragment rows as gemm3.hip (gemm_tile.h), five slots of 32 KiB
+//     (all 160 KiB of LDS) filled by global_load_lds with counted vmcnt, PAIRED: both k32 halves of a 128-byte operand line
+//     are requested back to back so that the L1 sends one request per line (see the kernel);
+//   * the (tile, K-step) sequence of a workgroup is FLATTENED: the ring never drains between tiles, the loop body is
+//     branch-free and every wait count is a constant;
 //   * the register epilogue of gemm_tile.h, once per 64-column slab of the wave's 128 columns.
-// Preconditions (dispatcher in gemm.hip): both operands k-major, K % 32 == 0, no split-K / accumulate.
+// What bounds it (and gemm3) is neither the matrix pipe nor instruction issue: with the DMAs removed the loop runs at 1600
+// TFLOP/s, with operands that hit in L2 a probe of the same K-step hides everything under the MFMAs; the kernel waits on L1 misses
+// in flight / their latency (80-100 lines per CU x 330-610 cycles -- the same as the vendor kernel, whose latency is 25 % lower).
+// Preconditions (dispatcher in gemm.hip): both operands k-major, K % 64 == 0, K >= 192, 16-byte aligned outputs, no split-K.
 #include "gemm_tile.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -24,16 +27,7 @@
 namespace g5 {
 using namespace g3;
 
-#ifndef G5_PAIR
-#define G5_PAIR 1         // 1: the two k32 halves of the same 128-byte lines are requested back to back (even K-steps issue 16
-#endif                    //    pieces, odd ones none; five slots); 0: one K-step's 8 pieces per step (four slots)
-#ifndef G5_NS
-#define G5_NS (G5_PAIR ? 5 : 4)
-#endif
-
-#ifndef G5_ABL
-#define G5_ABL 0          // timing-only ablations of the K-step (diagnostic builds; results are wrong): 1 no DMA issue, 2 no fragment
-#endif                    // reads, 4 no barrier, 8 no issue-side bookkeeping
+constexpr int G5_NS = 5;   // ring slots of 32 KiB: the whole 160 KiB of LDS
 
 #ifdef CTCLIP_G5_PROF
 // diagnostic build only (hipcc -DCTCLIP_G5_PROF, tools/gemm5_prof.py): per wave, shader-cycle sums of the K-step's segments
@@ -74,15 +68,15 @@ __global__ __launch_bounds__(256) void gemm5_kernel(Args g) {
   constexpr int STAGE = 2 * SUB;                     // a slot: the A tile (256 x 32 bf16) and the B tile behind it, 32 KiB
   constexpr int PPW = STAGE / 1024 / 4;              // 1 KiB DMA pieces per wave and slot: 8
   constexpr int NST = 2 * IM * (EPI == 0 ? 2 : EPI == 2 ? 3 : 4);   // 16-byte stores per wave of a full tile's register epilogue
-  constexpr bool PAIR = G5_PAIR != 0;
-  static_assert(!PAIR || NS == 5, "paired issue needs five slots");
-  // pieces that may stay in flight when K-step j + 2 must have landed.  Plain: K-steps j + 3 .. j + NS.  Paired (K-steps 2P + 4,
-  // 2P + 5 are issued during step 2P): after an even step j + 3, j + 4, j + 5, after an odd one j + 3, j + 4
-  constexpr int C_DMA = PAIR ? 3 * PPW : (NS - 2) * PPW;
-  constexpr int C_ODD = PAIR ? 2 * PPW : C_DMA;
-  constexpr int C_ST = C_DMA + NST > 63 ? 63 : C_DMA + NST;   // ... and an epilogue's stores behind them (vmcnt holds 6 bits)
-  constexpr int C_ODD_ST = C_ODD + NST > 63 ? 63 : C_ODD + NST;
-  constexpr int NPRO = PAIR ? 4 : NS;                // K-steps of the ring fill
+  static_assert(NS == 5, "the paired issue below is written for five slots");
+  // PAIRED ISSUE: the two k32 halves of the same 128-byte operand lines are requested back to back -- K-steps 2P + 4 and 2P + 5
+  // during step 2P, nothing during the odd steps -- so the second request merges with the first in the L1 and the L1 -> L2 request
+  // count is that of full lines (measured: profiles/r04_gemm5.txt sections 6, 7; one K-step's pieces per step with four slots
+  // was 5-9 % slower).  The two K-steps of a pair are issued piece by piece INTERLEAVED, so a K-step is only known complete
+  // when its whole pair is: when K-step j + 2 must have landed, what may stay in flight is the one pair issued after its pair.
+  constexpr int C_DMA = 2 * PPW;
+  constexpr int C_ST = C_DMA + NST > 63 ? 63 : C_DMA + NST;   // ... and an epilogue's stores behind it (vmcnt holds 6 bits)
+  constexpr int NPRO = 4;                            // K-steps of the ring fill: two pairs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm5_kernel(Args g) {
   // operand's last row (two registers instead of one per piece: every register of this kernel is spoken for)
   uint32_t voff0, vlast;
   const uint32_t rowstep = (uint32_t)(16 * ld * 2);
-  uint32_t half1 = 64;                               // the second k32 half of a line (paired form), kept in a register: an immediate
+  uint32_t half1 = 64;                               // the second k32 half of a line, kept in a register: an immediate
   asm volatile("" : "+s"(half1));                    // offset of a global_load_lds is added to the LDS address as well
   int itile = blockIdx.x, ik = 0, islot = 0;
   auto locate_issue = [&](int t) {
@@ -120,29 +114,24 @@ __global__ __launch_bounds__(256) void gemm5_kernel(Args g) {
   };
   // after the wave's PPW pieces of a K-step have been issued: next K-step, next tile of this workgroup; past the last tile the
   // last K-step is issued again (into a slot nobody reads any more), which keeps the loop body and the wait counts uniform
-  auto advance_issue = [&]() {                       // (paired form: by two K-steps; nk is even)
-    constexpr int D = PAIR ? 2 : 1;
-    islot = islot + D >= NS ? islot + D - NS : islot + D;
-    if ((ik += D) < nk) { ibase += D * BK * 2; return; }
+  auto advance_issue = [&]() {                       // by a pair of K-steps (nk is even)
+    islot = islot + 2 >= NS ? islot + 2 - NS : islot + 2;
+    if ((ik += 2) < nk) { ibase += 2 * BK * 2; return; }
     const int nt = itile + (int)gridDim.x;
     if (nt < total) { itile = nt; ik = 0; locate_issue(nt); }
-    else ik = nk - D;
+    else ik = nk - 2;
   };
-  // piece i of the K-step(s) at the issue position: plain -> slot islot; paired -> the k32 half at ibase into slot islot and the
-  // other half of the same lines (64 bytes further) into the next slot, back to back, so that the second request finds the
-  // line in the L1 or already on its way
+  // piece i of the pair at the issue position: the k32 half at ibase into slot islot and the other half of the same lines (64
+  // bytes further) into the next slot, back to back
   auto issue_piece = [&](int i) {
-    const uint32_t d0 = lds0 + (uint32_t)(islot * STAGE) + dst0 + i * 1024;
     const uint32_t v = min(voff0 + (uint32_t)i * rowstep, vlast);
-    G3_GLDS(ibase + v, d0);
-    if constexpr (PAIR) {
-      const int s1 = islot + 1 == NS ? 0 : islot + 1;
-      G3_GLDS(ibase + (v + half1), lds0 + (uint32_t)(s1 * STAGE) + dst0 + i * 1024);
-    }
+    const int s1 = islot + 1 == NS ? 0 : islot + 1;
+    G3_GLDS(ibase + v, lds0 + (uint32_t)(islot * STAGE) + dst0 + i * 1024);
+    G3_GLDS(ibase + (v + half1), lds0 + (uint32_t)(s1 * STAGE) + dst0 + i * 1024);
   };
   locate_issue(itile);
 #pragma unroll
-  for (int t = 0; t < NPRO; t += (PAIR ? 2 : 1)) {
+  for (int t = 0; t < NPRO; t += 2) {
 #pragma unroll
     for (int j = 0; j < PPW; ++j) issue_piece(j);
     advance_issue();
@@ -187,24 +176,21 @@ __global__ __launch_bounds__(256) void gemm5_kernel(Args g) {
         if constexpr (ZERO) mfma_zero(acc[i][jj], fbc[jj], fa[i]);
         else mfma_acc(acc[i][jj], fbc[jj], fa[i]);
       }
-      if (!(G5_ABL & 2)) {
       fa[i] = *(const bf16x8*)(st + offA + i * 1024);
       if (i < IM - 1) fbn[i] = *(const bf16x8*)(st + offB(i));
       if (i == IM - 2) fbn[JN - 1] = *(const bf16x8*)(st + offB(JN - 1));
-      }
-      if (!(G5_ABL & 1) && !(PAIR && ODD)) issue_piece(i);
+      if constexpr (!ODD) issue_piece(i);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(G5_ABL & 8) && !(PAIR && ODD)) advance_issue();
+    if constexpr (!ODD) advance_issue();
     cslot = nslot;
     G5_SEG(0); G5_CNT(5);
     // own pieces of the K-step after the next landed (it is read during the next step, behind this barrier)
-    if (post > 0) { if (ODD) wait_vm<C_ODD_ST>(); else wait_vm<C_ST>(); --post; }
-    else { if (ODD) wait_vm<C_ODD>(); else wait_vm<C_DMA>(); }
+    if (post > 0) { wait_vm<C_ST>(); --post; } else wait_vm<C_DMA>();
     G5_SEG(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of slot `nslot` retired before the barrier that frees it
     G5_SEG(2);
-    if (!(G5_ABL & 4)) G5_BAR();
+    G5_BAR();
     G5_SEG(3);
   };
   using T_ = std::true_type;
