@@ -560,12 +560,16 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
         // few LDS instructions below), read-modify-write, release.  LDS executes a wave's instructions in order, so the
         // releasing store is performed after the tile's stores.
         unsigned* lk = lock_l + t;
+        bool got = false;
         for (int spins = 0; spins < (1 << 22); ++spins) {
           unsigned old = 1u;
           if (lane == 0) old = atomicCAS(lk, 0u, 1u);
-          if (__builtin_amdgcn_readfirstlane(old) == 0u) break;
+          if (__builtin_amdgcn_readfirstlane(old) == 0u) { got = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
+        // a lock is held for a dozen LDS instructions; 4 M sleeping spins without getting it means it was never released: abort the
+        // launch (the caller sees a launch failure) rather than update the tile unlocked and free a lock this wave does not hold
+        if (!got) __builtin_trap();
         asm volatile("" ::: "memory");
         float4* dt = dbias_l + t * 256 + lane;
 #pragma unroll

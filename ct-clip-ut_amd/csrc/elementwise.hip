@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void bert_embed_fwd_kernel(const long* __restr
 //   d(pos)[p]   += sum over the sequences b, in order, of dy[b L + p]                      one thread per (p, 4 columns)
 //   d(type)[v]  += sum of dy[r] over the rows with token_type v                            chunk partials + ordered sum
 //   d(word)[id] += sum of dy[r] over the rows with ids[r] == id, in row order              one workgroup per row: the FIRST
-//       row of every id owns the sum -- it scans the id list for its later occurrences (list kept in LDS, in row order)
+//       row of every id (first[id], an integer atomic min) owns the sum and walks the rows behind it (bert_embed_bwd_word_kernel)
 __global__ __launch_bounds__(256) void bert_embed_bwd_pos_kernel(const float* __restrict__ dy, float* __restrict__ dpos,
                                                                  long rows, int L, int H4) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -304,37 +304,71 @@ __global__ __launch_bounds__(256) void bert_embed_bwd_type_kernel(const long* __
   for (int v = 0; v < ntypes; ++v) partials[((long)blockIdx.y * ntypes + v) * H + c] = acc[v];
 }
 
-__global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const long* __restrict__ ids, const float* __restrict__ dy,
-                                                                  float* __restrict__ dword, int rows, int H) {
-  extern __shared__ int emb_list[];                         // rows of this id, ascending
-  __shared__ int found, wave_cnt[4], list_len;
+// first[id] = the first row that holds id (integer atomic min: the result does not depend on the order of arrival)
+__global__ __launch_bounds__(256) void bert_embed_first_fill_kernel(int* __restrict__ first, long vocab) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < vocab) first[i] = 0x7fffffff;
+}
+__global__ __launch_bounds__(256) void bert_embed_first_kernel(const long* __restrict__ ids, int* __restrict__ first, int rows,
+                                                               long vocab) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const long id = ids[r];
+  if (id >= 0 && id < vocab) atomicMin(first + id, r);
+}
+// One workgroup per row; the workgroup of the FIRST row of an id owns that id's sum.  It walks the rows behind it 256 at a time,
+// collects the rows with its id in an LDS window (ascending) and, whenever the window is full, adds their dy rows to register
+// accumulators in that order: any number of rows, any number of repeats, bit-reproducible.  Cost: (distinct ids) x (rows behind
+// their first occurrence) id reads from L2 -- 45 056 rows of random ids (88 reports x 512 tokens) read ~4 GB, ~1 ms.
+constexpr int EMB_WIN = 2048, EMB_NC = 8;            // window entries; column blocks of 256 per pass (hidden <= 2048 in one pass)
+__global__ __launch_bounds__(256) void bert_embed_bwd_word_kernel(const long* __restrict__ ids, const int* __restrict__ first,
+                                                                  const float* __restrict__ dy, float* __restrict__ dword, int rows,
+                                                                  int H, long vocab) {
+  __shared__ int win[EMB_WIN];
+  __shared__ int wave_cnt[4], win_len;
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long id = ids[r];
-  if (tid == 0) { found = 0; list_len = 0; }
-  __syncthreads();
-  int dup = 0;
-  for (int j = tid; j < r; j += 256) dup |= (ids[j] == id);
-  if (dup) found = 1;                                       // benign race: every writer stores 1
-  __syncthreads();
-  if (found) return;                                        // an earlier row owns this id
-  for (int base = r; base < rows; base += 256) {
-    const int j = base + tid;
-    const bool hit = j < rows && ids[j] == id;
-    const unsigned long long m = __ballot(hit);
-    if (lane == 0) wave_cnt[wave] = __popcll(m);
+  if (id < 0 || id >= vocab || first[id] != r) return;      // (uniform) an earlier row owns this id
+  for (int c0 = 0; c0 < H; c0 += 256 * EMB_NC) {             // one pass for hidden <= 2048
+    float acc[EMB_NC];
+#pragma unroll
+    for (int q = 0; q < EMB_NC; ++q) acc[q] = 0.f;
+    auto flush = [&](int n) {
+      for (int i = 0; i < n; ++i) {
+        const float* row = dy + (long)win[i] * H + c0 + tid;
+#pragma unroll
+        for (int q = 0; q < EMB_NC; ++q)
+          if (c0 + tid + 256 * q < H) acc[q] += row[256 * q];
+      }
+    };
+    if (tid == 0) win_len = 0;
     __syncthreads();
-    int off = list_len;
-    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-    if (hit) emb_list[off + __popcll(m & ((1ull << lane) - 1ull))] = j;
+    for (int base = r; base < rows; base += 256) {
+      const int j = base + tid;
+      const bool hit = j < rows && ids[j] == id;
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wave_cnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = win_len;
+      for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+      if (hit) win[off + __popcll(m & ((1ull << lane) - 1ull))] = j;
+      __syncthreads();
+      const int n = win_len + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      __syncthreads();
+      if (n + 256 > EMB_WIN) {                                // the next 256 rows might not fit: empty the window
+        flush(n);
+        __syncthreads();
+        if (tid == 0) win_len = 0;
+      } else if (tid == 0) {
+        win_len = n;
+      }
+      __syncthreads();
+    }
+    flush(win_len);
+#pragma unroll
+    for (int q = 0; q < EMB_NC; ++q)
+      if (c0 + tid + 256 * q < H) dword[id * H + c0 + tid + 256 * q] += acc[q];
     __syncthreads();
-    if (tid == 0) list_len += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    __syncthreads();
-  }
-  const int n = list_len;
-  for (int c = tid; c < H; c += 256) {
-    float acc = 0.f;
-    for (int i = 0; i < n; ++i) acc += dy[(long)emb_list[i] * H + c];
-    dword[id * H + c] += acc;
   }
 }
 }  // namespace
@@ -349,16 +383,19 @@ int ctclip_bert_embed_fwd(const long* ids, const long* token_type, const float* 
   CTCLIP_CHECK_LAUNCH();
 }
 int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* dy, float* dword, float* dpos,
-                          float* dtype, long rows, int L, int hidden, int type_vocab, float* partials, void* stream) {
+                          float* dtype, long rows, int L, int hidden, int type_vocab, long vocab, float* partials,
+                          void* stream) {
   if (rows <= 0) return 0;
-  if ((hidden & 3) || L <= 0 || rows % L || type_vocab < 1 || type_vocab > EMB_NT || !partials || rows > (1L << 30))
+  // everything is validated before the first launch: nothing has been added to any gradient when an error is returned
+  if ((hidden & 3) || L <= 0 || rows % L || type_vocab < 1 || type_vocab > EMB_NT || !partials || rows > (1L << 30) ||
+      vocab < 1 || vocab > kPartialsFloats)
     return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bert_embed_bwd_pos_kernel, dim3((unsigned)(((long)L * (hidden / 4) + 255) / 256)), dim3(256), 0, st, dy,
-                     dpos, rows, L, hidden / 4);
   long maxchunks = kPartialsFloats / ((long)type_vocab * hidden);
   if (maxchunks > 64) maxchunks = 64;
   if (maxchunks < 1) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bert_embed_bwd_pos_kernel, dim3((unsigned)(((long)L * (hidden / 4) + 255) / 256)), dim3(256), 0, st, dy,
+                     dpos, rows, L, hidden / 4);
   long rpc = (rows + maxchunks - 1) / maxchunks;
   if (rpc < 32) rpc = 32;
   const int nchunks = (int)((rows + rpc - 1) / rpc);
@@ -367,10 +404,12 @@ int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   if (int r = ctclip_reduce_partials(partials, nchunks, (long)type_vocab * hidden, type_vocab * hidden, dtype, st)) return r;
-  const size_t lds = (size_t)rows * sizeof(int);
-  if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
-  if (lds > 65536) hipFuncSetAttribute((const void*)bert_embed_bwd_word_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(bert_embed_bwd_word_kernel, dim3((unsigned)rows), dim3(256), lds, st, ids, dy, dword, (int)rows, hidden);
+  // d(word): the scratch now holds first[vocab] (the token-type partials above have been consumed in stream order)
+  int* first = (int*)partials;
+  hipLaunchKernelGGL(bert_embed_first_fill_kernel, dim3((unsigned)((vocab + 255) / 256)), dim3(256), 0, st, first, vocab);
+  hipLaunchKernelGGL(bert_embed_first_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, ids, first, (int)rows, vocab);
+  hipLaunchKernelGGL(bert_embed_bwd_word_kernel, dim3((unsigned)rows), dim3(256), 0, st, ids, first, dy, dword, (int)rows, hidden,
+                     vocab);
   CTCLIP_CHECK_LAUNCH();
 }
 }

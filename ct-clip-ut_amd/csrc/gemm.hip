@@ -494,7 +494,9 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
     if (split_k > 1) part = splitk_ws;
   }
   auto finish = [&](int e, int splits) -> int {                        // second stage of the workspace form
-    if (e || !part) return e;
+    // one split (the launchers clamp the count to the K-steps there are): the kernel has accumulated straight into C and the
+    // workspace was never written
+    if (e || !part || splits <= 1) return e;
     return ctclip_reduce_partials(part, splits, (long)M * N, (int)((long)M * N), (float*)C, (hipStream_t)stream);
   };
   {

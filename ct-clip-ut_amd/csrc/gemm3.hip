@@ -449,7 +449,10 @@ int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* b
                            long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                            int hm_n, int hm_heads, hipStream_t st) {
   using namespace g3;
-  if (hm_n > 0 && (c_fp32 || act != 0 || hm_heads <= 0 || (M % hm_n) || (N & 63) || (N / 32) % hm_heads || (((uintptr_t)C) & 15)))
+  // (the epilogue divides the row by hm_n with a 32-bit multiply-high: exact while row * hm_n < 2^32, and the magic of hm_n = 1
+  // does not fit 32 bits)
+  if (hm_n > 0 && (c_fp32 || act != 0 || hm_heads <= 0 || (M % hm_n) || (N & 63) || (N / 32) % hm_heads || (((uintptr_t)C) & 15) ||
+                   hm_n < 2 || (long)M * hm_n >= (1L << 32)))
     return (int)hipErrorInvalidValue;
   if (act < 0 || act > 3) return (int)hipErrorInvalidValue;
   if (act == 2 && (c_fp32 || bias || resid || !G || (N & 63) || (ldc & 7) || (ldg & 7) || (((uintptr_t)C) & 15) ||

@@ -61,7 +61,7 @@ class BertEmbedFn(Function):
         dword, k3 = ops.grad_slot(p_word)                 # 30522 x 768: scatter-add straight into the arena
         dpos, k4 = ops.grad_slot(p_pos)
         dtype_, k5 = ops.grad_slot(p_type)
-        hip.bert_embed_bwd(ids, tt if tt.numel() else None, de, dword, dpos, dtype_, rows, L, Hd, p_type.shape[0])
+        hip.bert_embed_bwd(ids, tt if tt.numel() else None, de, dword, dpos, dtype_, rows, L, Hd, p_type.shape[0], nw)
         r = ops._ret
         return None, None, r(dword, k3), r(dpos, k4), r(dtype_, k5), r(dlw, k1), r(dlb, k2), None
 

@@ -153,14 +153,23 @@ class Visualizations:
                     cls = model.encode_text({k: v.to(dev) for k, v in text_tokens.items()})[:1]
             alphas = torch.linspace(0, 1, steps, device=dev)
             total = torch.zeros_like(image)
-            for i0 in range(0, steps, ig_batch):
-                a = alphas[i0:i0 + ig_batch].view(-1, 1, 1, 1, 1)
-                x = (baseline + a * diff).detach().requires_grad_()
-                with torch.enable_grad():
-                    sim = model(None, x, cls)[0]
-                    sim[:, 0].sum().backward()
-                total += x.grad.sum(dim=0, keepdim=True)
-                model.zero_grad(set_to_none=False)
+            # This is an INPUT-gradient pass: the parameter gradients it leaves in the arena are thrown away.  Under a process
+            # group the trainer's GradSync would start bucket all-reduces as they are produced -- unmatched if only some ranks
+            # attribute, and racing the zero_grad below -- so every synchroniser the parameters are tagged with is put into
+            # no_sync() for the duration (DDP's rule for a backward that must not communicate).
+            import contextlib
+            syncs = {id(s_): s_ for s_ in (getattr(p, "_ctclip_sync", None) for p in model.parameters()) if s_ is not None}
+            with contextlib.ExitStack() as stack:
+                for s_ in syncs.values():
+                    stack.enter_context(s_.no_sync())
+                for i0 in range(0, steps, ig_batch):
+                    a = alphas[i0:i0 + ig_batch].view(-1, 1, 1, 1, 1)
+                    x = (baseline + a * diff).detach().requires_grad_()
+                    with torch.enable_grad():
+                        sim = model(None, x, cls)[0]
+                        sim[:, 0].sum().backward()
+                    total += x.grad.sum(dim=0, keepdim=True)
+                    model.zero_grad(set_to_none=False)
         finally:
             model.gather_negatives = gathered
             model.train(was_training)

@@ -296,10 +296,12 @@ int ctclip_dropout_bwd(const float* g, float* d, void* d_bf16, long n, float p, 
 /* ---- BERT embeddings (transformers BertEmbeddings): word[ids] + pos[0..L) + type[token_type] ---- */
 int ctclip_bert_embed_fwd(const long* ids, const long* token_type, const float* word, const float* pos, const float* type,
                           float* out, long rows, int L, int hidden, void* stream);
-/* backward: no atomics -- d(pos) one owner per entry, d(type) chunk partials + ordered sum, d(word) summed by the first row of
- * every id over its later occurrences in row order: bit-reproducible.  rows % L == 0, rows <= 38 400, type_vocab <= 4. */
+/* backward: no float atomics -- d(pos) one owner per entry, d(type) chunk partials + ordered sum, d(word) summed by the first row
+ * of every id over its later occurrences in row order (LDS windows: any number of rows): bit-reproducible.  vocab = rows of the
+ * word table (<= CTCLIP_PARTIALS_FLOATS: the scratch holds one int per id; ids outside [0, vocab) are ignored).  rows % L == 0,
+ * type_vocab <= 4.  Everything is validated before the first launch. */
 int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* dy, float* dword, float* dpos,
-                          float* dtype, long rows, int L, int hidden, int type_vocab, float* partials, void* stream);
+                          float* dtype, long rows, int L, int hidden, int type_vocab, long vocab, float* partials, void* stream);
 
 /* ---- volume ingest (src/utils/preprocess.py:84-152, model_type "ctclip"): raw scan [H,W,D] (f32 or i16) -> HU rescale
  * -> permute to [D,H,W] -> trilinear resample to (rD,rH,rW) (align_corners=False) -> clamp/1000 -> centre crop / pad with

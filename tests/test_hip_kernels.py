@@ -1102,7 +1102,7 @@ def test_bert_embedding_backward_without_atomics(hip):
     outs = []
     for _ in range(3):
         dw, dp, dt = base["w"].clone(), base["p"].clone(), base["t"].clone()
-        hip.bert_embed_bwd(ids, tt, dy, dw, dp, dt, rows, L, H, NT)
+        hip.bert_embed_bwd(ids, tt, dy, dw, dp, dt, rows, L, H, NT, V)
         outs.append((dw, dp, dt))
     check("d(word)", outs[0][0], ref_w, 1e-5)
     check("d(position)", outs[0][1], ref_p, 1e-5)
@@ -1110,9 +1110,35 @@ def test_bert_embedding_backward_without_atomics(hip):
     for o in outs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
     dw, dp, dt = base["w"].clone(), base["p"].clone(), base["t"].clone()
-    hip.bert_embed_bwd(ids, None, dy, dw, dp, dt, rows, L, H, NT)        # no token types given: all rows are type 0
+    hip.bert_embed_bwd(ids, None, dy, dw, dp, dt, rows, L, H, NT, V)     # no token types given: all rows are type 0
     check("d(token type), tt = None", dt[0], base["t"][0] + dy.sum(0), 1e-5)
     assert torch.equal(dt[1], base["t"][1])
+
+
+def test_bert_embedding_backward_at_the_reference_text_length(hip):
+    """The reference tokenises to 512 tokens (CTClipTrainer max_text_length): 88 reports x 512 = 45 056 rows, more than any LDS
+    list of rows could hold -- the word gradient walks the rows in windows.  Padding makes one id ([PAD]) tens of thousands of rows
+    long (many windows), the rest is random over a BERT-sized vocabulary; against index_add, twice bit-identical."""
+    B, L, H, V = 88, 512, 64, 30522
+    rows = B * L
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(1, V, (rows,), generator=g)
+    lens = torch.randint(32, L + 1, (B,), generator=g)
+    ids.view(B, L)[torch.arange(L)[None] >= lens[:, None]] = 0           # [PAD]
+    ids = ids.to(DEV)
+    dy = rnd(rows, H, seed=130)
+    ref = torch.zeros(V, H, device=DEV, dtype=torch.float64).index_add_(0, ids, dy.double()).float()
+    outs = []
+    for _ in range(2):
+        dw, dp, dt = torch.zeros(V, H, device=DEV), torch.zeros(L, H, device=DEV), torch.zeros(2, H, device=DEV)
+        hip.bert_embed_bwd(ids, None, dy, dw, dp, dt, rows, L, H, 2, V)
+        outs.append((dw, dp, dt))
+    check("d(word), 45 056 rows", outs[0][0], ref, 2e-5)
+    check("d(position)", outs[0][1], dy.view(B, L, H).double().sum(0).float(), 2e-5)
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    with pytest.raises(RuntimeError):                                     # a word table larger than the scratch: refused before any launch
+        hip.bert_embed_bwd(ids, None, dy, dw, dp, dt, rows, L, H, 2, 1 << 22)
+    assert all(torch.equal(a, b) for a, b in zip((dw, dp, dt), outs[1]))
 
 
 # ---------------------------------------------------------------------------------------------- ordered (reproducible) sums

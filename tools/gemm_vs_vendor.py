@@ -48,14 +48,26 @@ def timed(fn, n):
 
 
 def _sysfs():
-    pw = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + \
-        glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")
-    sc = glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")
-    return (pw[0] if pw else None), (sc[0] if sc else None)
+    """hwmon power and pp_dpm_sclk of THIS process's GPU: the box shows all eight cards in sysfs, so the card is matched by the
+    PCI address torch reports for device 0."""
+    pr = torch.cuda.get_device_properties(0)
+    want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    for card in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+        try:
+            dev = os.path.realpath(os.path.join(card, "device"))
+        except OSError:
+            continue
+        if want not in dev:
+            continue
+        pw = glob.glob(os.path.join(dev, "hwmon/hwmon*/power1_average")) + glob.glob(os.path.join(dev, "hwmon/hwmon*/power1_input"))
+        cap = glob.glob(os.path.join(dev, "hwmon/hwmon*/power1_cap"))
+        sc = os.path.join(dev, "pp_dpm_sclk")
+        return (pw[0] if pw else None), (sc if os.path.exists(sc) else None), (cap[0] if cap else None), dev
+    return None, None, None, None
 
 
 def sample_power(stop, out):
-    pw, sc = _sysfs()
+    pw, sc, _, _ = _sysfs()
     while not stop.is_set():
         p = f = None
         try:
@@ -89,6 +101,10 @@ def power_loop(fn, seconds):
         (statistics.mean(fs) if fs else float("nan"))
 
 
+if POWER > 0:
+    _pw, _sc, _cap, _dev = _sysfs()
+    capw = (int(open(_cap).read()) / 1e6) if _cap else float("nan")
+    print(f"# power samples: {_pw} (cap {capw:.0f} W), clock: {_sc}", flush=True)
 print(f"# {torch.cuda.get_device_name(0)}  B={B} (tokens {T})  rounds {R}  torch {torch.__version__}  randn operands", flush=True)
 print(f"# {'shape':12s} {'M':>8s} {'N':>5s} {'K':>8s} | ours TF med  best | vendor TF med  best | ours/vendor", flush=True)
 for name, M, N, K, akm, bkm, cf in SHAPES:
