@@ -380,20 +380,56 @@ __global__ __launch_bounds__(512) void mfma_probe_kernel(float* __restrict__ out
 }
 }  // namespace
 
-// diagnostic: plain 16-byte-per-lane streaming copy -- the HBM rate this part sustains (read + write bytes), the yardstick
-// next to the 8 TB/s datasheet figure for the HBM-bound kernels (tubelet gather, PEG, LayerNorm, Adam)
+// diagnostic: the HBM rate this part sustains -- the yardstick next to the 8 TB/s datasheet figure for the HBM-bound kernels
+// (tubelet gather, PEG, LayerNorm, Adam).  Eight independent 16-byte accesses per lane are in flight before the first is used
+// (a one-load-in-flight grid-stride loop read 4.95 TB/s where this repo's own LayerNorm kernels move 5.6-5.7), non-temporal,
+// each workgroup walking whole 32 KiB blocks.  MODE 0 copy (read + write bytes), 1 read only, 2 write only.
 namespace {
-__global__ __launch_bounds__(256) void copy_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n16) {
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n16; e += (long)gridDim.x * 256) dst[e] = src[e];
+typedef __attribute__((ext_vector_type(4))) float probe_f4;
+template <int MODE>
+__global__ __launch_bounds__(256) void stream_probe_kernel(const probe_f4* __restrict__ src, probe_f4* __restrict__ dst, long n16,
+                                                           float* __restrict__ sink) {
+  constexpr int U = 8;
+  const long per = 256L * U;                                       // 16-byte elements per workgroup and iteration
+  probe_f4 keep = {0.f, 0.f, 0.f, 0.f};
+  for (long b0 = (long)blockIdx.x * per; b0 < n16; b0 += (long)gridDim.x * per) {
+    probe_f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long e = b0 + u * 256 + threadIdx.x;
+      if (MODE != 2) v[u] = e < n16 ? __builtin_nontemporal_load(src + e) : keep;
+      else v[u] = keep;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long e = b0 + u * 256 + threadIdx.x;
+      if (MODE != 1) { if (e < n16) __builtin_nontemporal_store(v[u], dst + e); }
+      else keep += v[u];
+    }
+  }
+  if (MODE == 1 && keep.x + keep.y + keep.z + keep.w == 123.456f) sink[0] = keep.x;      // keep the loads alive
+}
+int stream_probe(int mode, const void* src, void* dst, long bytes, hipStream_t st) {
+  if (bytes <= 0) return 0;
+  if ((bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return (int)hipErrorInvalidValue;
+  const long n16 = bytes / 16;
+  const long want = (n16 + 2047) / 2048;
+  const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+  if (mode == 0) hipLaunchKernelGGL(stream_probe_kernel<0>, dim3(grid), dim3(256), 0, st, (const probe_f4*)src, (probe_f4*)dst, n16, nullptr);
+  else if (mode == 1) hipLaunchKernelGGL(stream_probe_kernel<1>, dim3(grid), dim3(256), 0, st, (const probe_f4*)src, nullptr, n16, (float*)dst);
+  else hipLaunchKernelGGL(stream_probe_kernel<2>, dim3(grid), dim3(256), 0, st, nullptr, (probe_f4*)dst, n16, nullptr);
+  CTCLIP_CHECK_LAUNCH();
 }
 }  // namespace
 
 extern "C" int ctclip_probe_copy(const void* src, void* dst, long bytes, void* stream) {
-  if (bytes <= 0) return 0;
-  if ((bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(copy_probe_kernel, dim3(grid_for(bytes / 16, 16384)), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)src, (float4*)dst, bytes / 16);
-  CTCLIP_CHECK_LAUNCH();
+  return stream_probe(0, src, dst, bytes, (hipStream_t)stream);
+}
+/* mode 1: reads `bytes` from src (dst: any 16-byte aligned scratch of >= 4 bytes, written only if a sum happens to match);
+ * mode 2: writes `bytes` of zeros to dst (src unused, may alias dst) */
+extern "C" int ctclip_probe_stream(const void* src, void* dst, long bytes, int mode, void* stream) {
+  if (mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+  return stream_probe(mode, mode == 2 ? dst : src, dst, bytes, (hipStream_t)stream);
 }
 
 extern "C" int ctclip_probe_mfma(float* out, int blocks, int iters, void* stream) {

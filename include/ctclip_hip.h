@@ -313,9 +313,11 @@ int ctclip_ingest_volume(const void* raw, int raw_is_i16, int H, int W, int D, f
  * what the matrix pipes sustain at the clock the part holds under load (no reference counterpart) ---- */
 int ctclip_probe_mfma(float* out, int blocks, int iters, void* stream);
 
-/* ---- diagnostic: 16-byte-per-lane streaming copy of `bytes` (multiple of 16, 16-byte aligned pointers): the HBM rate the
- * part sustains, (read + write) bytes / time (no reference counterpart) ---- */
+/* ---- diagnostic: streaming copy of `bytes` (multiple of 16, 16-byte aligned pointers), eight independent 16-byte non-temporal
+ * accesses in flight per lane: the HBM rate the part sustains, (read + write) bytes / time (no reference counterpart).
+ * ctclip_probe_stream: mode 0 the same copy, 1 pure read of src (dst: >= 16 bytes of scratch), 2 pure write of dst ---- */
 int ctclip_probe_copy(const void* src, void* dst, long bytes, void* stream);
+int ctclip_probe_stream(const void* src, void* dst, long bytes, int mode, void* stream);
 
 #ifdef __cplusplus
 }
