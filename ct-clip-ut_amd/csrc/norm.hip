@@ -60,9 +60,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   for (int i = 0; i < LN_NV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
-      const float4 g = ((const float4*)gamma)[c];
-      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (beta) b = ((const float4*)beta)[c];
+      float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gamma) g = ((const float4*)gamma)[c];            // gamma == NULL: the plain normalised rows (affine part folded into
+      if (gamma && beta) b = ((const float4*)beta)[c];     // the projection that follows: ctclip_patch_affine_fold)
       float4 o;
       o.x = (v[i].x - mu) * rs * g.x + b.x;
       o.y = (v[i].y - mu) * rs * g.y + b.y;
@@ -177,6 +177,61 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
   float* prow = partials + (long)blockIdx.x * width;                 // [dgamma (dim) | dbeta (dim)]
   for (int i = threadIdx.x; i < width; i += 256)
     prow[i] = (lnred[i] + lnred[2 * dim + i]) + (lnred[4 * dim + i] + lnred[6 * dim + i]);
+}
+
+// LayerNorm backward from the saved NORMALISED rows (bf16, the operand of the projection that follows -- its affine part folded
+// into that projection's weight, so dy here is the gradient w.r.t. xhat and there is no d(gamma) / d(beta) to reduce):
+//   dx = dres + dres2 + rstd (dy - mean(dy) - xhat mean(dy xhat))
+// Reads 2 + 2 (+ 4 + 2) bytes per element where the form above reads the f32 input row (4) as well, keeps no partial sums and
+// needs neither x nor the mean: the f32 input of the LayerNorm is not kept for the backward at all.
+template <int LN_NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_xhat_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ xhat,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                                 const bf16_t* __restrict__ dres2, float* __restrict__ dx,
+                                                                 bf16_t* __restrict__ dx16, int rows, int dim) {
+  const int lane = threadIdx.x & 63;
+  const int nv = dim >> 2;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+    const float rs = rstd[row];
+    const long base = (long)row * dim;
+    float4 xh[LN_NV], gg[LN_NV], rres[LN_NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_NV; ++i) {
+      const int c = lane + i * 64;
+      rres[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < nv) {
+        if (dres) rres[i] = ((const float4*)(dres + base))[c];
+        if (dres2) {
+          const float4 r2 = ld_bf16x4(dres2 + base + 4 * c);
+          rres[i].x += r2.x; rres[i].y += r2.y; rres[i].z += r2.z; rres[i].w += r2.w;
+        }
+        xh[i] = ld_bf16x4(xhat + base + 4 * c);
+        gg[i] = ld_bf16x4(dy + base + 4 * c);
+        s1 += (gg[i].x + gg[i].y) + (gg[i].z + gg[i].w);
+        s2 += (gg[i].x * xh[i].x + gg[i].y * xh[i].y) + (gg[i].z * xh[i].z + gg[i].w * xh[i].w);
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)dim, m2 = wave_sum(s2) / (float)dim;
+#pragma unroll
+    for (int i = 0; i < LN_NV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        float4 o;
+        o.x = rs * (gg[i].x - m1 - xh[i].x * m2) + rres[i].x;
+        o.y = rs * (gg[i].y - m1 - xh[i].y * m2) + rres[i].y;
+        o.z = rs * (gg[i].z - m1 - xh[i].z * m2) + rres[i].z;
+        o.w = rs * (gg[i].w - m1 - xh[i].w * m2) + rres[i].w;
+        if (dx) ((float4*)(dx + base))[c] = o;
+        if (dx16) {
+          uint2 p;
+          p.x = pack_bf16x2(o.x, o.y);
+          p.y = pack_bf16x2(o.z, o.w);
+          ((uint2*)(dx16 + base))[c] = p;
+        }
+      }
+    }
+  }
 }
 
 // element offset of (row, head) in a [rows, ld] row-major matrix (hm_n == 0) or in the head-major layout
@@ -382,6 +437,22 @@ int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* 
   if ((dim & 3) || dim > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
   return ln_bwd_launch<true>(dy_bf16, x, gamma, mean, rstd, dres, (const bf16_t*)dres2_bf16, dx, (bf16_t*)dx_bf16, dgamma,
                              dbeta, partials, rows, dim, 0, 0, (hipStream_t)stream);
+}
+
+int ctclip_layernorm_bwd_xhat(const void* dy_bf16, const void* xhat_bf16, const float* rstd, const float* dres,
+                              const void* dres2_bf16, float* dx, void* dx_bf16, int rows, int dim, void* stream) {
+  if (rows <= 0) return 0;
+  if ((dim & 3) || dim > 64 * 4 * LN_MAXV) return (int)hipErrorInvalidValue;
+  long blocks = ((long)rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+#define LN_BWX(NV)                                                                                                         \
+  hipLaunchKernelGGL(layernorm_bwd_xhat_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,            \
+                     (const bf16_t*)dy_bf16, (const bf16_t*)xhat_bf16, rstd, dres, (const bf16_t*)dres2_bf16, dx,           \
+                     (bf16_t*)dx_bf16, rows, dim)
+  const int nv = (dim / 4 + 63) / 64;
+  if (nv <= 1) LN_BWX(1); else if (nv <= 2) LN_BWX(2); else if (nv <= 3) LN_BWX(3); else if (nv <= 4) LN_BWX(4); else LN_BWX(16);
+#undef LN_BWX
+  CTCLIP_CHECK_LAUNCH();
 }
 
 int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_norm, long rows, int heads, int dhead,

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void patch_affine_fold_kernel(const float* __r
     float w = 0.f;
     if (f < F) {
       w = W[(long)n * F + f];
-      s = fmaf(w, beta[f], s);
+      if (beta) s = fmaf(w, beta[f], s);
       w *= gamma[f];
     }
     Wg[(long)n * ldw + f] = f32_to_bf16(w);
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void patch_affine_fold_kernel(const float* __r
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) bfold[n] = (bias ? bias[n] : 0.f) + ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+  if (threadIdx.x == 0 && bfold) bfold[n] = (bias ? bias[n] : 0.f) + ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
 }
 
 // backward: a workgroup owns 64 features, its four row lanes split the N output rows (combined in a fixed order)
@@ -253,10 +253,10 @@ __global__ __launch_bounds__(256) void patch_affine_bwd_kernel(const float* __re
   const int f = blockIdx.x * 64 + fl;
   float ag = 0.f, ab = 0.f;
   if (f < F) {
-    const float gm = gamma[f], bt = beta[f];
+    const float gm = gamma[f], bt = beta ? beta[f] : 0.f;
     for (int n = rl; n < N; n += 4) {
       const long e = (long)n * F + f;
-      const float g = G[e], w = W[e], d = db[n];
+      const float g = G[e], w = W[e], d = db ? db[n] : 0.f;
       ag = fmaf(w, g, ag);
       ab = fmaf(w, d, ab);
       dW[e] += fmaf(g, gm, d * bt);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void patch_affine_bwd_kernel(const float* __re
   __syncthreads();
   if (rl == 0 && f < F) {
     dgamma[f] += (red[0][0][fl] + red[0][1][fl]) + (red[0][2][fl] + red[0][3][fl]);
-    dbeta[f] += (red[1][0][fl] + red[1][1][fl]) + (red[1][2][fl] + red[1][3][fl]);
+    if (dbeta) dbeta[f] += (red[1][0][fl] + red[1][1][fl]) + (red[1][2][fl] + red[1][3][fl]);
   }
 }
 

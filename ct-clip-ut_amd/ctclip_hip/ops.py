@@ -445,10 +445,13 @@ class AttentionFn(Function):
         hm = attn_head_major_ok(n, dh, dp, dim, heads, want_probs)
         qmult = float(scale) * LOG2E
         x2 = _c(x).reshape(M, dim)
-        n1, _, mean, rstd = layernorm(x2, gamma.detach(), None, 1e-5)
+        # production head size: gamma is folded into the q projection (shadow "wqg"), the saved GEMM operand n1 is the PLAIN
+        # normalised row and the backward needs neither x nor the mean (ctclip_layernorm_bwd_xhat)
+        fold = "wqg" in sh
+        n1, _, mean, rstd = layernorm(x2, None if fold else gamma.detach(), None, 1e-5)
         x16 = aux.get("x16")
         xb = x16.reshape(M, dim) if (x16 is not None and x16.numel() == M * dim and x16.is_contiguous()) else cast16(x2)
-        q = gemm(n1, sh["wq"], M, inner, dim)
+        q = gemm(n1, sh["wqg" if fold else "wq"], M, inner, dim)
         qinv = torch.empty(M, heads, dtype=F32, device=dev)
         kinv = torch.empty(M, heads, dtype=F32, device=dev)
         o = torch.empty(M, inner, dtype=BF16, device=dev)
@@ -489,7 +492,8 @@ class AttentionFn(Function):
             hip.attn_probs(qh, kh, lse, bias_dense, None, probs, nseq, n, heads, dp, inner, inner, LN2)
         else:
             probs = x.new_empty(0)
-        ctx.save_for_backward(x2, gamma, mean, rstd, n1, xb, q, kv, qh, kh, qinv, kinv, o, lse,
+        keep_x = x2.new_empty(0) if fold else x2                  # folded: the f32 input row is not kept for the backward
+        ctx.save_for_backward(keep_x, gamma, mean, rstd, n1, xb, q, kv, qh, kh, qinv, kinv, o, lse,
                               bias_dense if bias_dense is not None else x2.new_empty(0))
         ctx.sh, ctx.cfg, ctx.aux, ctx.shape, ctx.hm = sh, cfg, aux, (nseq, n, dim), hm
         ctx.params = (gamma, wq, wkv, q_scale, k_scale, wout)
@@ -572,14 +576,23 @@ class AttentionFn(Function):
             hip.headnorm_bwd(dkh, k_raw, kinv, sh["k_scale"], dkv, gks, M, heads, dp, inner, k_ld, 2 * inner, 1.0, k_hm)
             # both data gradients leave their (store-bound, K = 256 / 512) GEMMs in bf16; the f32 residual-path gradient
             # dy2 is added inside the LayerNorm backward, so the residual stream itself never passes through bf16
-            dn1 = dgrad(dq, sh["wq"], M, inner, dim, out_dtype=BF16, wT16=sh.get("wqT"))
-            wgrad(dq, n1, inner, dim, M, out=gwq)
+            fold = "wqg" in sh
+            dn1 = dgrad(dq, sh["wqg" if fold else "wq"], M, inner, dim, out_dtype=BF16, wT16=sh.get("wqgT" if fold else "wqT"))
+            if fold:
+                # G = dq^T xhat is the one weight-gradient product; d(Wq) = G gamma, d(gamma) = sum_n Wq G (exact, no division)
+                G = wgrad(dq, n1, inner, dim, M)
+                hip.patch_affine_bwd(G, None, p_wq.detach(), gamma.detach(), None, gwq, gg, None, inner, dim)
+            else:
+                wgrad(dq, n1, inner, dim, M, out=gwq)
             dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, out_dtype=BF16, wT16=sh.get("wkvT"))
             wgrad(dkv, xb, 2 * inner, dim, M, out=gwkv)
             # x came from a PEG (it handed us its bf16 copy): this gradient goes back into the PEG backward, which reads
             # f32 only, so a bf16 mirror of it would be a gigabyte written for nobody
             dx16 = torch.empty(M, dim, dtype=BF16, device=dev) if aux.get("x16") is None else None
-            hip.layernorm_bwd_bf16(dn1, x2, gamma, mean, rstd, dy2 if residual else None, dxkv, dx, dx16, gg, None, M, dim)
+            if fold:
+                hip.layernorm_bwd_xhat(dn1, n1, rstd, dy2 if residual else None, dxkv, dx, dx16, M, dim)
+            else:
+                hip.layernorm_bwd_bf16(dn1, x2, gamma, mean, rstd, dy2 if residual else None, dxkv, dx, dx16, gg, None, M, dim)
             dxr = dx.reshape(nseq, n, dim)
             return (_tag16(dxr, dx16) if dx16 is not None else dxr, _ret(gg, d6), _ret(gwq, d3), _ret(gwkv, d4), _ret(gqs, d1), _ret(gks, d2),
                     _ret(gwo, d5), dbias, None, None, None)

@@ -172,6 +172,7 @@ class Attention(nn.Module):
         H, dh = self.heads, self.dim_head
         dp = ops.head_pad(dh)
         wq, wkv, wo, qs, ks = self.to_q.weight, self.to_kv.weight, self.to_out.weight, self.q_scale, self.k_scale
+        gamma = self.norm.gamma
 
         def build():
             inner = H * dh
@@ -186,9 +187,15 @@ class Attention(nn.Module):
             }
             # transposed copies of the (small) weights: dgrad then has the forward's k-major x k-major layout
             d.update(wqT=d["wq"].t().contiguous(), wkvT=d["wkv"].t().contiguous(), woutT=d["wout"].t().contiguous())
+            if dp == dh:
+                # the LayerNorm's gamma folded into the q projection (q = xhat (Wq gamma)^T, attention.py:140,142): the GEMM
+                # operand is the plain normalised row, which is then all the LayerNorm backward needs (ops.AttentionFn)
+                wqg = torch.empty(inner, self.dim, dtype=BF16, device=wq.device)
+                hip.patch_affine_fold(wq.detach(), None, gamma.detach(), None, wqg, None, inner, self.dim, self.dim)
+                d.update(wqg=wqg, wqgT=wqg.t().contiguous())
             return d
 
-        return self._shadow.get("attn", (wq, wkv, wo, qs, ks), build)
+        return self._shadow.get("attn", (wq, wkv, wo, qs, ks, gamma), build)
 
     def forward(self, x, mask=None, context=None, attn_bias=None, residual: bool = False, x16=None):
         _need_cuda(x, "Attention")

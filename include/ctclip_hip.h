@@ -79,7 +79,8 @@ int ctclip_vq_topk(const void* A, const void* B, float* part_val, int* part_idx,
 int ctclip_vq_topk_grouped(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda, long ldb,
                            int code_groups, void* stream);
 
-/* ---- LayerNorm: attention.py:27-34 (beta==NULL), attention.py:46, ctvit.py:51, BertLayerNorm ---- */
+/* ---- LayerNorm: attention.py:27-34 (beta==NULL), attention.py:46, ctvit.py:51, BertLayerNorm; gamma == NULL (then beta is
+ * ignored): the plain normalised rows ---- */
 int ctclip_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                          float* mean, float* rstd, int rows, int dim, float eps, void* stream);
 /* dx = dres + LN'(dy); optional bf16 copy of dx; dgamma/dbeta accumulated (dbeta may be NULL). */
@@ -100,6 +101,13 @@ int ctclip_layernorm_swap_bwd(const float* dy, const float* x, const float* gamm
 int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* dres, const void* dres2_bf16, float* dx, void* dx_bf16, float* dgamma,
                               float* dbeta, int rows, int dim, float* partials, void* stream);
+
+/* LayerNorm backward from the saved NORMALISED rows xhat (bf16; ctclip_layernorm_fwd with gamma == NULL writes them) when the
+ * affine part has been folded into the projection that follows (ctclip_patch_affine_fold / _bwd give d(gamma), d(beta) from
+ * the weight-gradient product): dy is the gradient w.r.t. xhat, dx = dres + dres2 + rstd (dy - mean(dy) - xhat mean(dy xhat)).
+ * Neither the f32 input row nor the mean is read (attention.py:27-34,140). */
+int ctclip_layernorm_bwd_xhat(const void* dy_bf16, const void* xhat_bf16, const float* rstd, const float* dres,
+                              const void* dres2_bf16, float* dx, void* dx_bf16, int rows, int dim, void* stream);
 
 /* ---- per-head cosine normalisation: y = x/|x| * scale[d] * mult   (attention.py:151-153,155) ----
  * x_hm_n / y_hm_n > 0: that operand is in the HEAD-MAJOR layout [sequence][head][token][dhead] with x_hm_n tokens per
@@ -226,6 +234,8 @@ int ctclip_patch_ln_fwd(const void* volume, int volume_is_bf16, const float* gam
  * Backward, from G[N,F] = dz^T xhat (f32, the one weight-gradient product) and db[N] = colsum(dz):
  *   dW[n][f] += G gamma[f] + db[n] beta[f];  dgamma[f] += sum_n W[n][f] G[n][f];  dbeta[f] += sum_n W[n][f] db[n]
  * -- exact, and no [tokens, F] gradient is ever formed.  W is [N][F] f32 contiguous (nn.Linear weight). */
+/* Any Linear behind a LayerNorm can use the pair (the attention blocks' q projection does: attention.py:140,142): bias, beta,
+ * bias_folded, db and dbeta may be NULL (a LayerNorm without beta, a Linear without bias). */
 int ctclip_patch_affine_fold(const float* W, const float* bias, const float* gamma, const float* beta, void* Wg_bf16,
                              float* bias_folded, int N, int F, long ldw, void* stream);
 int ctclip_patch_affine_bwd(const float* G, const float* db, const float* W, const float* gamma, const float* beta, float* dW,

@@ -1082,6 +1082,30 @@ def test_gelu_tail_saturates(hip):
     assert torch.equal(m[big], h[big])                                   # Phi = 1 exactly: gelu(x) = x
 
 
+def test_layernorm_backward_from_normalised_rows(hip):
+    """ctclip_layernorm_bwd_xhat: the LayerNorm backward when gamma has been folded into the following projection -- from the saved
+    bf16 normalised rows alone (neither x nor the mean), against autograd through F.layer_norm without affine part on the same
+    rows; plus the two residual-path terms.  ctclip_layernorm_fwd with gamma = NULL writes exactly those rows."""
+    rows, dim = 777, 512
+    x = rnd(rows, dim, seed=140) * 3 + 0.5
+    xh16 = torch.empty(rows, dim, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    hip.layernorm_fwd(x, None, None, xh16, None, mean, rstd, rows, dim, 1e-5)
+    xr = x.clone().requires_grad_(True)
+    ref_y = torch.nn.functional.layer_norm(xr, (dim,), eps=1e-5)
+    check("plain normalised rows", xh16, ref_y, 1e-2)
+    dy = bf(rnd(rows, dim, seed=141))
+    ref_y.backward(dy.float())
+    dres, dres2 = rnd(rows, dim, seed=142), bf(rnd(rows, dim, seed=143))
+    dx, dx16 = torch.empty(rows, dim, device=DEV), torch.empty(rows, dim, device=DEV, dtype=torch.bfloat16)
+    hip.layernorm_bwd_xhat(dy, xh16, rstd, dres, dres2, dx, dx16, rows, dim)
+    want = xr.grad + dres + dres2.float()
+    check("dx from xhat", dx, want, 5e-3)                  # xhat enters its own backward rounded to bf16
+    check("dx bf16 copy", dx16, want, 1e-2)
+    hip.layernorm_bwd_xhat(dy, xh16, rstd, None, None, dx, None, rows, dim)
+    check("dx, no residual terms", dx, xr.grad, 5e-3)
+
+
 def test_bert_embedding_backward_without_atomics(hip):
     """ctclip_bert_embed_bwd (transformers BertEmbeddings backward): d(word) / d(position) / d(token type) against
     torch's index_add on the same inputs -- ids with many repeats (and one id used by every row of a sequence), on top of
