@@ -431,6 +431,9 @@ int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* b
 int ctclip_gemm5_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                         long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                         int hm_n, int hm_heads, hipStream_t st);
+int ctclip_gemm3_launch_ln(const void* A, const void* B, float* C, void* C16, const float* resid, int M, int N, int K, long lda,
+                           long ldb, long ldc, long ldc16, long ldr, const void* xhat, long ldx, const float* c1, const float* c2,
+                           hipStream_t st);
 int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
                         float alpha, float* part, hipStream_t st);
 int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
@@ -562,6 +565,15 @@ int ctclip_gemm_bf16_headmajor(const void* A, const void* B, void* C, int M, int
   if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true) || (K % 32) || n_tokens <= 0) return (int)hipErrorInvalidValue;
   return launch_kk(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, N, 0, 0, 1.0f, 0, nullptr, 0, n_tokens, heads,
                    (hipStream_t)stream);
+}
+
+// dx = A[M,K] B[N,K]^T - c1[row] - xhat[row][col] c2[row] + resid  (f32, optional bf16 copy): a data-gradient product with the
+// LayerNorm backward applied in its epilogue (include/ctclip_hip.h).  Always the LDS-DMA kernel of gemm3.hip.
+int ctclip_gemm_bf16_lnbwd(const void* A, const void* B, float* dx, void* dx_bf16, int M, int N, int K, long lda, long ldb,
+                           const void* xhat, const float* c1, const float* c2, const float* dres, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true) || (K % 32)) return (int)hipErrorInvalidValue;
+  return ctclip_gemm3_launch_ln(A, B, dx, dx_bf16, dres, M, N, K, lda, ldb, N, N, N, xhat, N, c1, c2, (hipStream_t)stream);
 }
 
 // scores[m][n] = sum_k A[m][k] B[n][k], never materialised; for every column n writes 16 candidates: the top-4 of each

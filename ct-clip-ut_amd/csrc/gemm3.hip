@@ -77,7 +77,7 @@ __device__ long g_stamp_cap = 0;
 //   0 plain -> bf16   1 plain -> f32   (both: alpha, bias, residual, erf-GELU when g.act == 1)   2 FF1 + GEGLU   3 FF2 dgrad + GEGLU backward
 template <int TBN, int EPI>
 __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g) {
-  constexpr bool F32OUT = EPI == 1;
+  constexpr bool F32OUT = EPI == 1 || EPI == 4;     // identity N-fragment rows: a lane holds 4 contiguous f32 columns
   constexpr int WN = TBN / 64, WM = 8 / WN;            // wave grid: 2 x 4 or 4 x 2
   constexpr int IM = BM / WM / 16, JN = 4;             // MFMA tiles per wave: 8 x 4 or 4 x 4 (the slab is always 64 columns)
   constexpr int TNS = (TBN == 256) ? G3_NS256 : 3;     // ring stages
@@ -433,6 +433,52 @@ __global__ __launch_bounds__(512, 2) void vq_topk3_kernel(VqArgs g) {
 
 }  // namespace g3
 
+namespace {
+// shape: 256 x 256 (one workgroup per CU) everywhere but the f32-output products with a very short matrix loop (the
+// out-projection, K = 256: write-back-bound), where two 256 x 128 workgroups per CU overlap one's stores with the other's
+// loop.  CTCLIP_GEMM3_BN=128|256 forces one shape (experiments).
+int g3_launch(g3::Args& g, int epi, int c_fp32, hipStream_t st) {
+  using namespace g3;
+  const int M = g.M, N = g.N, K = g.K;
+  static const int forced = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM3_BN"); return e ? atoi(e) : 0; }();
+  const int bn = (forced == 128 || forced == 256) ? forced : ((c_fp32 && K <= 256) ? 128 : 256);
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + bn - 1) / bn;
+#define G3_LAUNCH(BN_, EPI_, LDS_)                                                                                        \
+  do {                                                                                                                    \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set) {                                                                                                      \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<BN_, EPI_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)(LDS_));                                                                    \
+      if (e != hipSuccess) return (int)e;                                                                                 \
+      attr_set = true;                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((gemm3_kernel<BN_, EPI_>), dim3(grid), dim3(512), (LDS_), st, g);                                  \
+  } while (0)
+#define G3_SHAPES(EPI_)                                                                                                   \
+  do {                                                                                                                    \
+    if (bn == 256) G3_LAUNCH(256, EPI_, (size_t)G3_NS256 * (SUB + 256 * BK * 2)); /* 128 KiB: one workgroup per CU */           \
+    else G3_LAUNCH(128, EPI_, (size_t)3 * (SUB + 128 * BK * 2));           /* 72 KiB: two workgroups per CU */           \
+  } while (0)
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? (n / 8) * 8 : 256;                 // a multiple of 8 keeps a workgroup's tiles on one XCD's run
+  }();
+  const long total = (long)g.tiles_m * g.tiles_n;
+  const long resident = (long)cus * (bn == 256 ? 1 : 2);
+  static const bool persist = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM3_PERSIST"); return !e || atoi(e) != 0; }();   // 0: one tile per workgroup (A/B)
+  const int grid = (int)((total < resident || !persist) ? total : resident);
+  if (epi == 0) G3_SHAPES(0);
+  else if (epi == 1) G3_SHAPES(1);
+  else if (epi == 2) G3_SHAPES(2);
+  else if (epi == 3) G3_SHAPES(3);
+  else G3_SHAPES(4);
+#undef G3_SHAPES
+#undef G3_LAUNCH
+  return (int)hipGetLastError();
+}
+}  // namespace
+
 // called by ctclip_gemm_bf16 (gemm.hip): k-major x k-major, K % 32 == 0, plain (non-accumulating) output
 int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                            long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
@@ -474,45 +520,25 @@ int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* b
     g.hm_magic = (uint32_t)(((1ull << 32) + (unsigned long long)hm_n - 1) / (unsigned long long)hm_n);
     g.hm_part = (long)M * hm_heads * 32;
   }
-  // shape: 256 x 256 (one workgroup per CU) everywhere but the f32-output products with a very short matrix loop (the
-  // out-projection, K = 256: write-back-bound), where two 256 x 128 workgroups per CU overlap one's stores with the other's
-  // loop.  CTCLIP_GEMM3_BN=128|256 forces one shape (experiments).
-  static const int forced = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM3_BN"); return e ? atoi(e) : 0; }();
-  const int bn = (forced == 128 || forced == 256) ? forced : ((c_fp32 && K <= 256) ? 128 : 256);
-  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + bn - 1) / bn;
-#define G3_LAUNCH(BN_, EPI_, LDS_)                                                                                        \
-  do {                                                                                                                    \
-    static bool attr_set = false;                                                                                         \
-    if (!attr_set) {                                                                                                      \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<BN_, EPI_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)(LDS_));                                                                    \
-      if (e != hipSuccess) return (int)e;                                                                                 \
-      attr_set = true;                                                                                                    \
-    }                                                                                                                     \
-    hipLaunchKernelGGL((gemm3_kernel<BN_, EPI_>), dim3(grid), dim3(512), (LDS_), st, g);                                  \
-  } while (0)
-#define G3_SHAPES(EPI_)                                                                                                   \
-  do {                                                                                                                    \
-    if (bn == 256) G3_LAUNCH(256, EPI_, (size_t)G3_NS256 * (SUB + 256 * BK * 2)); /* 128 KiB: one workgroup per CU */           \
-    else G3_LAUNCH(128, EPI_, (size_t)3 * (SUB + 128 * BK * 2));           /* 72 KiB: two workgroups per CU */           \
-  } while (0)
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? (n / 8) * 8 : 256;                 // a multiple of 8 keeps a workgroup's tiles on one XCD's run
-  }();
-  const long total = (long)g.tiles_m * g.tiles_n;
-  const long resident = (long)cus * (bn == 256 ? 1 : 2);
-  static const bool persist = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM3_PERSIST"); return !e || atoi(e) != 0; }();   // 0: one tile per workgroup (A/B)
-  const int grid = (int)((total < resident || !persist) ? total : resident);
-  const int epi = act >= 2 ? act : (c_fp32 ? 1 : 0);
-  if (epi == 0) G3_SHAPES(0);
-  else if (epi == 1) G3_SHAPES(1);
-  else if (epi == 2) G3_SHAPES(2);
-  else G3_SHAPES(3);
-#undef G3_SHAPES
-#undef G3_LAUNCH
-  return (int)hipGetLastError();
+  return g3_launch(g, act >= 2 ? act : (c_fp32 ? 1 : 0), c_fp32, st);
+}
+
+// The f32 product with the LayerNorm backward applied in the epilogue (gemm_tile.h, EPI 4): C = A B^T - c1[row] - xhat c2[row]
+// + resid, optional bf16 copy.  Same preconditions as the plain launch plus 16-byte aligned C / C16 / resid and 8-byte aligned
+// xhat rows (N % 8 == 0): hipErrorInvalidValue otherwise -- there is no element-wise form of this epilogue.
+int ctclip_gemm3_launch_ln(const void* A, const void* B, float* C, void* C16, const float* resid, int M, int N, int K, long lda,
+                           long ldb, long ldc, long ldc16, long ldr, const void* xhat, long ldx, const float* c1, const float* c2,
+                           hipStream_t st) {
+  using namespace g3;
+  if (!xhat || !c1 || !c2 || (N & 7) || (((uintptr_t)C) & 15) || (ldc & 3) || (((uintptr_t)xhat) & 7) || (ldx & 3) ||
+      (C16 && ((((uintptr_t)C16) & 7) || (ldc16 & 3))) || (resid && ((((uintptr_t)resid) & 15) || (ldr & 3))))
+    return (int)hipErrorInvalidValue;
+  Args g{};
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.resid = resid;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
+  g.alpha = 1.0f; g.direct = 1;
+  g.xhat = (const bf16_t*)xhat; g.ldx = ldx; g.c1 = c1; g.c2 = c2; g.C16 = (bf16_t*)C16; g.ldc16 = ldc16;
+  return g3_launch(g, 4, 1, st);
 }
 
 #ifdef CTCLIP_G3_STAMPS

@@ -63,7 +63,7 @@ __device__ __forceinline__ void mfma_zero(f32x4& c, bf16x8 a, bf16x8 b) {      /
 
 template <int EPI, int NS>
 __global__ __launch_bounds__(256) void gemm5_kernel(Args g) {
-  constexpr bool F32OUT = EPI == 1;
+  constexpr bool F32OUT = EPI == 1 || EPI == 4;     // identity N-fragment rows: a lane holds 4 contiguous f32 columns
   constexpr int IM = 8, JN = 8, BN = 256;
   constexpr int STAGE = 2 * SUB;                     // a slot: the A tile (256 x 32 bf16) and the B tile behind it, 32 KiB
   constexpr int PPW = STAGE / 1024 / 4;              // 1 KiB DMA pieces per wave and slot: 8

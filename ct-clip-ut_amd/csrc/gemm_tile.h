@@ -27,6 +27,11 @@ struct Args {
   int hm_n, hm_heads;
   uint32_t hm_magic;
   long hm_part;
+  // EPI 4 (LayerNorm backward applied to the product, f32 out): C = alpha A B^T - c1[row] - xhat[row][col] c2[row] + resid, with an
+  // optional bf16 copy of C in C16 -- the row constants come from the producer of A (ctclip_headnorm_bwd_ln)
+  const bf16_t* xhat; long ldx;
+  const float* c1; const float* c2;
+  bf16_t* C16; long ldc16;
 };
 
 // [256 rows][32 k] bf16 tile, 64-byte rows, 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128 phase hit 16
@@ -117,10 +122,10 @@ __device__ __forceinline__ uint4 f4_bits(float a, float b, float c, float d) {
 // READS (residual, h) for row group i + 1 is requested before row group i is worked on (needs a second buffer).
 // GENERIC = false leaves out the element-wise path for unaligned outputs (the caller then only takes g.direct problems).
 // EPI: 0 plain -> bf16   1 plain -> f32   (both: alpha, bias, residual, erf-GELU when g.act == 1)   2 FF1 + GEGLU
-//      3 FF2 data gradient + GEGLU backward
+//      3 FF2 data gradient + GEGLU backward   4 the f32 form with the LayerNorm backward applied (Args::xhat, c1, c2)
 template <int EPI, int IM, int NJ, int J0, bool AHEAD, bool GENERIC = true>
 __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ], int rbase, int colw, int lane) {
-  constexpr bool F32OUT = EPI == 1;
+  constexpr bool F32OUT = EPI == 1 || EPI == 4, LNB = EPI == 4;
   const int ml = lane & 15, q4 = lane >> 4;
   const int act = EPI >= 2 ? EPI : g.act;
   if (g.direct) {
@@ -146,15 +151,34 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
         if (AHEAD) { if (i + 1 < IM) ld_resid(i + 1, rs[(i + 1) & 1]); }
         else ld_resid(i, rs[i & 1]);
         uint4 pk[4];
+        float k1 = 0.f, k2 = 0.f;                    // EPI 4: this lane's row constants
+        if constexpr (LNB) {
+          const int rowl = rbase + i * 16 + ml;
+          if (rowl < g.M) { k1 = g.c1[rowl]; k2 = g.c2[rowl]; }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int col = colw + 16 * j + 4 * q4;
           float x[4] = {acc[i][J0 + j][0] * g.alpha, acc[i][J0 + j][1] * g.alpha, acc[i][J0 + j][2] * g.alpha, acc[i][J0 + j][3] * g.alpha};
           if (g.bias && col < g.N) { const float4 bb = *(const float4*)(g.bias + col); x[0] += bb.x; x[1] += bb.y; x[2] += bb.z; x[3] += bb.w; }
+          if constexpr (LNB) {
+            const int rowl = rbase + i * 16 + ml;
+            uint2 xw = make_uint2(0u, 0u);
+            if (rowl < g.M && col < g.N) xw = *(const uint2*)(g.xhat + (long)rowl * g.ldx + col);
+            x[0] -= fmaf(__uint_as_float(xw.x << 16), k2, k1);
+            x[1] -= fmaf(__uint_as_float(xw.x & 0xffff0000u), k2, k1);
+            x[2] -= fmaf(__uint_as_float(xw.y << 16), k2, k1);
+            x[3] -= fmaf(__uint_as_float(xw.y & 0xffff0000u), k2, k1);
+          }
           const float4 r = rs[i & 1][j];
           x[0] += r.x; x[1] += r.y; x[2] += r.z; x[3] += r.w;
           if (act == 1) { x[0] = gelu_erf(x[0]); x[1] = gelu_erf(x[1]); x[2] = gelu_erf(x[2]); x[3] = gelu_erf(x[3]); }
           pk[j] = f4_bits(x[0], x[1], x[2], x[3]);
+          if constexpr (LNB) {
+            const int rowl = rbase + i * 16 + ml;
+            if (g.C16 && rowl < g.M && col < g.N)
+              *(uint2*)(g.C16 + (long)rowl * g.ldc16 + col) = make_uint2(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]));
+          }
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m) {              // columns 32 m .. 32 m + 31 of the slab: one 128-byte line per row

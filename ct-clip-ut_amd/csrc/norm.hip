@@ -284,12 +284,15 @@ __global__ __launch_bounds__(256) void headnorm_fwd_kernel(const bf16_t* __restr
 }
 
 // dx = inv * (du - u (u . du)),  u = x*inv,  du = dy * scale * mult ;  dscale[d] += sum dy * u * mult
-template <int LPH>
+// LNX (ctclip_headnorm_bwd_ln): the eight heads of a row are the 32 lanes of half a wave; besides dx the kernel writes the row
+// scaled by rstd and the two row constants of the LayerNorm backward that runs in the next GEMM's epilogue.
+struct HeadLnx { const float* rstd; const float* wbar; bf16_t* dxs; long lddxs; float* c1; float* c2; float inv_dim; };
+template <int LPH, bool LNX = false>
 __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                            const float* __restrict__ inv_norm, const float* __restrict__ scale,
                                                            bf16_t* __restrict__ dx, float* __restrict__ partials,
                                                            long npairs, int H, long lddy, long ldx, long lddx, float mult,
-                                                           int x_hm) {
+                                                           int x_hm, HeadLnx lx) {
   __shared__ float red[256 / LPH][LPH * 8 + 1];                      // [pair slot of the workgroup][d]
   const int D = LPH * 8;
   const int sub = threadIdx.x % LPH;
@@ -324,13 +327,34 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restr
     }
 #pragma unroll
     for (int o = LPH >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-    if (ok) {
-      uint4 o;
-      uint32_t* ow = (uint32_t*)&o;
+    uint4 o = make_uint4(0, 0, 0, 0);
+    uint32_t* ow = (uint32_t*)&o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        ow[i] = pack_bf16x2(inv * (du[2 * i] - u[2 * i] * dot), inv * (du[2 * i + 1] - u[2 * i + 1] * dot));
-      *(uint4*)(dx + row * lddx + head * D + sub * 8) = o;
+    for (int i = 0; i < 4; ++i)
+      ow[i] = pack_bf16x2(inv * (du[2 * i] - u[2 * i] * dot), inv * (du[2 * i + 1] - u[2 * i + 1] * dot));
+    if (ok) *(uint4*)(dx + row * lddx + head * D + sub * 8) = o;
+    if constexpr (LNX) {
+      // H * LPH == 32: the lanes of this row are an aligned group of 32
+      const float rs = ok ? lx.rstd[row] : 0.f;
+      float s1 = 0.f, s2 = 0.f, v[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(ow[i] << 16); v[2 * i + 1] = __uint_as_float(ow[i] & 0xffff0000u);     // dx as the GEMM will read it
+        const float x0 = __uint_as_float(wx[i] << 16), x1 = __uint_as_float(wx[i] & 0xffff0000u);
+        const int k = head * D + sub * 8 + 2 * i;
+        s1 += v[2 * i] * lx.wbar[k] + v[2 * i + 1] * lx.wbar[k + 1];
+        s2 += v[2 * i] * x0 + v[2 * i + 1] * x1;
+      }
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+      if (ok) {
+        uint4 os;
+        uint32_t* osw = (uint32_t*)&os;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) osw[i] = pack_bf16x2(rs * v[2 * i], rs * v[2 * i + 1]);
+        *(uint4*)(lx.dxs + row * lx.lddxs + head * D + sub * 8) = os;
+        if (head == 0 && sub == 0) { lx.c1[row] = rs * lx.inv_dim * s1; lx.c2[row] = rs * lx.inv_dim * s2; }
+      }
     }
   }
 #pragma unroll
@@ -485,10 +509,29 @@ int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, co
   dim3 grid((unsigned)blocks), block(256);
   if (lph == 4)
     hipLaunchKernelGGL(headnorm_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
-                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n);
+                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n, HeadLnx{});
   else
     hipLaunchKernelGGL(headnorm_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
-                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n);
+                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n, HeadLnx{});
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  return ctclip_reduce_partials(partials, (int)blocks, dhead, dhead, dscale, (hipStream_t)stream);
+}
+
+int ctclip_headnorm_bwd_ln(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
+                           float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
+                           const float* rstd, const float* wbar, int ln_dim, void* dx_scaled, long lddxs, float* c1, float* c2,
+                           float* partials, void* stream) {
+  const long npairs = rows * heads;
+  if (npairs <= 0) return 0;
+  if (dhead != 32 || heads != 8 || !partials || !rstd || !wbar || !dx_scaled || !c1 || !c2 || ln_dim <= 0 || (lddxs & 7) ||
+      (((uintptr_t)dx_scaled) & 15))
+    return (int)hipErrorInvalidValue;
+  long blocks = (npairs + 63) / 64;
+  if (blocks > 2048) blocks = 2048;
+  HeadLnx lx{rstd, wbar, (bf16_t*)dx_scaled, lddxs, c1, c2, 1.0f / (float)ln_dim};
+  hipLaunchKernelGGL((headnorm_bwd_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+                     (const bf16_t*)x, inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, 0, lx);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return ctclip_reduce_partials(partials, (int)blocks, dhead, dhead, dscale, (hipStream_t)stream);

@@ -517,7 +517,12 @@ class AttentionFn(Function):
         dyb = _get16(dy)
         dqh = torch.empty(M, inner, dtype=BF16, device=dev)
         dkh = torch.empty(M, inner, dtype=BF16, device=dev)
-        dkv = torch.empty(M, 2 * inner, dtype=BF16, device=dev)
+        # fused form (production head size, 8 heads): [rstd dq | dk | dv] is ONE bf16 operand of the block's input-gradient GEMM, whose
+        # epilogue applies the LayerNorm backward (ctclip_gemm_bf16_lnbwd); dkv is its last 2 inner columns
+        fused = "wcat" in sh and dp == dh == 32 and heads == 8 and dim % 8 == 0
+        dcat = torch.empty(M, 3 * inner, dtype=BF16, device=dev) if fused else None
+        dkv = dcat[:, inner:] if fused else torch.empty(M, 2 * inner, dtype=BF16, device=dev)
+        lkv = dkv.stride(0)
         delta = torch.empty(nseq, heads, n, dtype=F32, device=dev)
         dbias_dense = dtable = rel = None
         tsize = gh = gw = 0
@@ -540,12 +545,12 @@ class AttentionFn(Function):
             do = torch.empty(nseq, heads, n, dp, dtype=BF16, device=dev)
             hip.gemm_bf16_headmajor(dyb, sh["woutT"], do, M, inner, dim, dyb.stride(0), sh["woutT"].stride(0), n, heads)
             hip.attn_hm_bwd(qh, kh, kv[1], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, fast_dense, f_rel, fast_table,
-                            f_ts, f_gh, f_gw, nseq, n, heads, inner, inner, inner, 2 * inner)
+                            f_ts, f_gh, f_gw, nseq, n, heads, inner, inner, inner, lkv)
         else:
             do = dgrad(dyb, sh["wout"], M, dim, inner, out_dtype=BF16, wT16=sh.get("woutT"))
             hip.attn_bwd(qh, kh, kv[:, inner:], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, None,
                          fast_dense, f_rel, fast_table, f_ts, f_gh, f_gw, nseq, n, heads, dp,
-                         inner, inner, 2 * inner, inner, inner, inner, inner, 2 * inner, LN2)
+                         inner, inner, 2 * inner, inner, inner, inner, inner, lkv, LN2)
         if ordered:
             dense = dbias_dense if dbias_dense is not None else torch.zeros(heads, n, n, dtype=F32, device=dev)
             if hm:
@@ -572,11 +577,28 @@ class AttentionFn(Function):
             gwo, d5 = grad_slot(p_wout)
             gg, d6 = grad_slot(p_gamma)
             wgrad(dyb, o, dim, inner, M, out=gwo)
-            hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, inner, inner, qmult, 0)
-            hip.headnorm_bwd(dkh, k_raw, kinv, sh["k_scale"], dkv, gks, M, heads, dp, inner, k_ld, 2 * inner, 1.0, k_hm)
+            c1 = c2 = None
+            if fused:
+                c1 = torch.empty(M, dtype=F32, device=dev)
+                c2 = torch.empty(M, dtype=F32, device=dev)
+                hip.headnorm_bwd_ln(dqh, q, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, inner, inner, qmult,
+                                    rstd, sh["wbar"], dim, dcat, dcat.stride(0), c1, c2)
+            else:
+                hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, inner, inner, qmult, 0)
+            hip.headnorm_bwd(dkh, k_raw, kinv, sh["k_scale"], dkv, gks, M, heads, dp, inner, k_ld, lkv, 1.0, k_hm)
             # both data gradients leave their (store-bound, K = 256 / 512) GEMMs in bf16; the f32 residual-path gradient
             # dy2 is added inside the LayerNorm backward, so the residual stream itself never passes through bf16
             fold = "wqg" in sh
+            if fused:
+                G = wgrad(dq, n1, inner, dim, M)
+                hip.patch_affine_bwd(G, None, p_wq.detach(), gamma.detach(), None, gwq, gg, None, inner, dim)
+                wgrad(dkv, xb, 2 * inner, dim, M, out=gwkv)
+                dx16 = torch.empty(M, dim, dtype=BF16, device=dev) if aux.get("x16") is None else None
+                hip.gemm_bf16_lnbwd(dcat, sh["wcat"], dx, dx16, M, dim, 3 * inner, dcat.stride(0), sh["wcat"].stride(0), n1, c1, c2,
+                                    dy2 if residual else None)
+                dxr = dx.reshape(nseq, n, dim)
+                return (_tag16(dxr, dx16) if dx16 is not None else dxr, _ret(gg, d6), _ret(gwq, d3), _ret(gwkv, d4), _ret(gqs, d1),
+                        _ret(gks, d2), _ret(gwo, d5), dbias, None, None, None)
             dn1 = dgrad(dq, sh["wqg" if fold else "wq"], M, inner, dim, out_dtype=BF16, wT16=sh.get("wqgT" if fold else "wqT"))
             if fold:
                 # G = dq^T xhat is the one weight-gradient product; d(Wq) = G gamma, d(gamma) = sum_n Wq G (exact, no division)

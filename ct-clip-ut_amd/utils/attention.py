@@ -193,6 +193,9 @@ class Attention(nn.Module):
                 wqg = torch.empty(inner, self.dim, dtype=BF16, device=wq.device)
                 hip.patch_affine_fold(wq.detach(), None, gamma.detach(), None, wqg, None, inner, self.dim, self.dim)
                 d.update(wqg=wqg, wqgT=wqg.t().contiguous())
+                # one k-major operand [dim, inner + 2 inner] for the block's input gradient dx = [rstd dq | dkv] [Wqg ; Wkv]
+                # (ctclip_gemm_bf16_lnbwd), and the row sums of Wqg its LayerNorm-backward constants need
+                d.update(wcat=torch.cat((d["wqgT"], d["wkvT"]), 1).contiguous(), wbar=wqg.float().sum(1).contiguous())
             return d
 
         return self._shadow.get("attn", (wq, wkv, wo, qs, ks, gamma), build)

@@ -109,6 +109,18 @@ int ctclip_layernorm_bwd_bf16(const void* dy_bf16, const float* x, const float* 
 int ctclip_layernorm_bwd_xhat(const void* dy_bf16, const void* xhat_bf16, const float* rstd, const float* dres,
                               const void* dres2_bf16, float* dx, void* dx_bf16, int rows, int dim, void* stream);
 
+/* The LayerNorm backward of an attention block inside the data-gradient GEMM that feeds it (attention.py:140-142 backward): with
+ * the LayerNorm's gamma folded into the q projection (Wqg), the block's input gradient is
+ *   dx = rstd (dq Wqg - mean(.) - xhat mean(. xhat)) + dkv Wkv + dres
+ *      = [rstd dq | dkv] [Wqg ; Wkv] - c1[row] - xhat[row][:] c2[row] + dres,      c1 = rstd/dim sum_k dq_k wbar_k,
+ *                                                                                  c2 = rstd/dim sum_k dq_k q_k
+ * (wbar_k = sum_c Wqg[k][c]; q = xhat Wqg^T is the raw projection the head-norm backward reads anyway): ONE product over
+ * K = inner + 2 inner whose epilogue subtracts the two row terms -- no [tokens, dim] gradient leaves the chip twice and there is
+ * no separate LayerNorm-backward pass.  A: [M, K] bf16 (row-scaled dq and c1 / c2 come from ctclip_headnorm_bwd_ln), B: [N, K]
+ * bf16, xhat: [M, N] bf16 contiguous, dres: [M, N] f32 or NULL; dx [M, N] f32, dx_bf16 optional.  K % 32 == 0, N % 8 == 0. */
+int ctclip_gemm_bf16_lnbwd(const void* A, const void* B, float* dx, void* dx_bf16, int M, int N, int K, long lda, long ldb,
+                           const void* xhat, const float* c1, const float* c2, const float* dres, void* stream);
+
 /* ---- per-head cosine normalisation: y = x/|x| * scale[d] * mult   (attention.py:151-153,155) ----
  * x_hm_n / y_hm_n > 0: that operand is in the HEAD-MAJOR layout [sequence][head][token][dhead] with x_hm_n tokens per
  * sequence (rows % x_hm_n == 0; its ld is ignored) -- the operand layout of ctclip_attn_hm_*; 0: row-major [rows, ld]. */
@@ -117,6 +129,14 @@ int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_n
 int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
                         float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
                         int x_hm_n, float* partials, void* stream);
+/* the same for the q path of a block whose LayerNorm backward runs inside ctclip_gemm_bf16_lnbwd: also writes
+ * dx_scaled[row][:] = rstd[row] dx[row][:] (bf16, row stride lddxs) and the two row constants of that epilogue,
+ * c1[row] = rstd/ln_dim sum_k dx_k wbar_k and c2[row] = rstd/ln_dim sum_k dx_k x_k (dx as rounded to bf16).
+ * heads * dhead == 256 and dhead == 32 (a row's heads are the 32 lanes of half a wave), x row-major. */
+int ctclip_headnorm_bwd_ln(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
+                           float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
+                           const float* rstd, const float* wbar, int ln_dim, void* dx_scaled, long lddxs, float* c1, float* c2,
+                           float* partials, void* stream);
 
 /* ---- fused attention (attention.py:155-180; BertSelfAttention) ----------------------------------
  * q,k,v,o: [nseq*n, ld] bf16, head h in columns h*dhead.. ; dhead in {32,64}.

@@ -1106,6 +1106,57 @@ def test_layernorm_backward_from_normalised_rows(hip):
     check("dx, no residual terms", dx, xr.grad, 5e-3)
 
 
+def test_attention_input_gradient_with_layernorm_backward_in_the_gemm(hip):
+    """ctclip_headnorm_bwd_ln + ctclip_gemm_bf16_lnbwd: the input gradient of an attention block as ONE product
+    [rstd dq | dk | dv] [Wqg ; Wkv] whose epilogue applies the LayerNorm backward, against f32 torch math of the chain it replaces
+    (head-norm backward -> q / kv data gradients -> LayerNorm backward + residual terms; attention.py:140-153 backward).  Ragged
+    row count, with and without the residual gradient and the bf16 copy."""
+    M, dim, H, D = 1000, 512, 8, 32
+    inner = H * D
+    mult = 8.0 * 1.4426950408889634
+    x = rnd(M, dim, seed=150) * 2 + 0.3
+    gamma = 1 + 0.2 * rnd(dim, seed=151)
+    wq, wkv = rnd(inner, dim, seed=152) * 0.05, rnd(2 * inner, dim, seed=153) * 0.05
+    qs = 1 + 0.1 * rnd(D, seed=154)
+    # forward quantities the way the block saves them
+    xh16 = torch.empty(M, dim, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.layernorm_fwd(x, None, None, xh16, None, mean, rstd, M, dim, 1e-5)
+    wqg = torch.empty(inner, dim, device=DEV, dtype=torch.bfloat16)
+    hip.patch_affine_fold(wq, None, gamma, None, wqg, None, inner, dim, dim)
+    q16 = bf(xh16.float() @ wqg.float().t())                                  # raw q as the projection GEMM rounds it
+    qinv = 1.0 / q16.float().view(M, H, D).norm(dim=-1).clamp_min(1e-12)      # [M, H]
+    dqh, dkv = bf(rnd(M, inner, seed=155)), bf(rnd(M, 2 * inner, seed=156))
+    dres = rnd(M, dim, seed=157)
+    # reference: f32 autograd of l2norm-and-scale, then the two data gradients and the LayerNorm backward
+    qr = q16.float().view(M, H, D).clone().requires_grad_(True)
+    (torch.nn.functional.normalize(qr, dim=-1) * qs * mult).backward(dqh.float().view(M, H, D))
+    dq_ref = qr.grad.reshape(M, inner)
+    dq16 = bf(dq_ref)
+    dn = dq16.float() @ wqg.float()                                           # gradient w.r.t. xhat
+    xh = xh16.float()
+    ln = rstd[:, None] * (dn - dn.mean(1, keepdim=True) - xh * (dn * xh).mean(1, keepdim=True))
+    want = ln + dkv.float() @ bf(wkv).float() + dres
+    # fused path
+    dcat = torch.empty(M, 3 * inner, device=DEV, dtype=torch.bfloat16)
+    dcat[:, inner:] = dkv
+    dq = torch.empty(M, inner, device=DEV, dtype=torch.bfloat16)
+    gqs = torch.zeros(D, device=DEV)
+    c1, c2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    wbar = wqg.float().sum(1).contiguous()
+    hip.headnorm_bwd_ln(dqh, q16, qinv.contiguous(), qs, dq, gqs, M, H, D, inner, inner, inner, mult, rstd, wbar, dim, dcat,
+                        3 * inner, c1, c2)
+    check("dq (head-norm backward)", dq, dq_ref, 1e-2)
+    check("rstd-scaled dq", dcat[:, :inner], rstd[:, None] * dq.float(), 1e-2)
+    wcat = torch.cat((wqg.t(), bf(wkv).t()), 1).contiguous()                  # [dim, 3 inner]
+    dx, dx16 = torch.empty(M, dim, device=DEV), torch.empty(M, dim, device=DEV, dtype=torch.bfloat16)
+    hip.gemm_bf16_lnbwd(dcat, wcat, dx, dx16, M, dim, 3 * inner, 3 * inner, 3 * inner, xh16, c1, c2, dres)
+    check("dx = LN'(dq Wqg) + dkv Wkv + dres", dx, want, 6e-3)
+    check("bf16 copy of dx", dx16, want, 1.2e-2)
+    hip.gemm_bf16_lnbwd(dcat, wcat, dx, None, M, dim, 3 * inner, 3 * inner, 3 * inner, xh16, c1, c2, None)
+    check("dx without the residual gradient", dx, want - dres, 6e-3)
+
+
 def test_bert_embedding_backward_without_atomics(hip):
     """ctclip_bert_embed_bwd (transformers BertEmbeddings backward): d(word) / d(position) / d(token type) against
     torch's index_add on the same inputs -- ids with many repeats (and one id used by every row of a sequence), on top of
