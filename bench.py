@@ -125,7 +125,11 @@ def gemm_work_fns():
 
     def geglu_bwd(dY, W, H, S, M, inner, K, *rest):            # FF2 dgrad + GEGLU backward: h read, d(h) written in place
         return {"flops": 2.0 * M * _unpad(inner) * K, "bytes": 2.0 * (M * K + inner * K) + 2.0 * M * 4 * inner}
-    return {"gemm_bf16": plain, "gemm_bf16_geglu": geglu, "gemm_bf16_geglu_bwd": geglu_bwd, "gemm_bf16_headmajor": headmajor}
+    def lnbwd(A, B, dx, dx16, M, N, K, *rest):       # [rstd dq | dk | dv] [Wqg ; Wkv] with the LayerNorm backward in the epilogue
+        return {"flops": 2.0 * M * N * K, "tag": "attn_proj",
+                "bytes": 2.0 * (M * K + N * K) + M * N * (4.0 + 2.0 + 4.0) + (2.0 * M * N if dx16 is not None else 0.0)}
+    return {"gemm_bf16": plain, "gemm_bf16_geglu": geglu, "gemm_bf16_geglu_bwd": geglu_bwd, "gemm_bf16_headmajor": headmajor,
+            "gemm_bf16_lnbwd": lnbwd}
 
 
 def other_work_fns():
@@ -181,12 +185,19 @@ def attention_block_aggregate(timed2, tags, nsteps, vit_cfg, peaks):
     def add(key, items):
         for ms, w in items:
             acc[key]["ms"] += ms; acc[key]["flops"] += w["flops"]; acc[key]["launches"] += 1
-    # launches per step through ctclip_gemm_bf16: spatial layers q + out (kv goes through the head-major entry), temporal q + kv + out
+    # launches per step through ctclip_gemm_bf16: forward -- spatial layers q + out (kv goes through the head-major entry), temporal
+    # q + kv + out; backward -- the q and kv data gradients of every layer are ONE launch of ctclip_gemm_bf16_lnbwd (with the
+    # LayerNorm backward in its epilogue), which leaves the temporal layers' out-projection data gradient here (the spatial ones
+    # go through the head-major entry)
+    lnb = list(timed2.get("ctclip_gemm_bf16_lnbwd", {}).get("items", []))
     nf_s, nf_t = 2 * sd, 3 * td
     for st in per_step(plain):
-        assert len(st) == 2 * (nf_s + nf_t), len(st)
+        assert len(st) == nf_s + nf_t + td, len(st)
         add("spatial_fwd", st[:nf_s]); add("temporal_fwd", st[nf_s:nf_s + nf_t])
-        add("temporal_bwd", st[nf_s + nf_t:nf_s + 2 * nf_t]); add("spatial_bwd", st[nf_s + 2 * nf_t:])
+        add("temporal_bwd", st[nf_s + nf_t:])
+    for st in per_step(lnb):                        # one per layer, temporal layers first
+        assert len(st) == sd + td, len(st)
+        add("temporal_bwd", st[:td]); add("spatial_bwd", st[td:])
     for st in per_step(hmaj):                       # spatial kv projection (forward), spatial out-projection data gradient (backward)
         assert len(st) == 2 * sd, len(st)
         add("spatial_fwd", st[:sd]); add("spatial_bwd", st[sd:])
@@ -201,7 +212,8 @@ def attention_block_aggregate(timed2, tags, nsteps, vit_cfg, peaks):
     out = {"bound": "mfma", "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
            "what": "q + kv + out projections and score / PV products of the CT-ViT attention blocks (SURVEY 8(d): 22.65 GF per spatial "
                    "and 14.84 GF per temporal layer and pair, forward); backward = data + weight gradients of the projections and the "
-                   "attention backward at 10 n^2 d flops per head; time = summed HIP-event durations of exactly those launches"}
+                   "attention backward at 10 n^2 d flops per head; time = summed HIP-event durations of exactly those launches (the "
+                   "backward's q + kv data-gradient launch also applies the block's LayerNorm backward in its epilogue)"}
     tot = {"fwd": [0.0, 0.0], "bwd": [0.0, 0.0]}
     for k, v in acc.items():
         tf = v["flops"] / (v["ms"] * 1e-3) / 1e12

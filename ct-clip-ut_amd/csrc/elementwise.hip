@@ -489,3 +489,96 @@ int ctclip_dropout_bwd(const float* g, float* d, void* d_bf16, long n, float p, 
   CTCLIP_CHECK_LAUNCH();
 }
 }
+
+// ---- weight shadows: every kernel-layout copy of the model's parameters in ONE launch per optimiser step ------------------------
+// The GEMM kernels read bf16 (and transposed, zero-padded, block-interleaved, gamma-scaled) copies of the f32 master weights;
+// rebuilding them with framework ops took ~180 small launches per step.  Here a table of descriptors -- written once, when
+// the model is built -- drives one kernel: descriptor d copies a [rows, cols] source matrix (f32 or bf16) into its destination
+//   dst[(map(r)) * dst_ld + c]        or, transposed,   dst[c * dst_ld + map(r)]
+//   map(r) = r, or with blk > 0  (r / blk) * 2 blk + r % blk     (the [val blk | gate blk | ...] interleave of the GEGLU weight:
+//                                                                  the gate half's dst pointer starts blk rows / columns in)
+// multiplied by scale[c] when a column scale is given (a LayerNorm's gamma folded into the projection behind it), as bf16 or
+// f32; ROWSUM instead writes dst[r] = sum_c bf16(src[r][c] scale[c]) (f32).  A workgroup takes one 32 x 64 tile; tile_start[d] is
+// the first tile of descriptor d.
+namespace {
+struct ShadowDesc { const void* src; void* dst; long rows, cols, src_ld, dst_ld, flags; const float* scale; };
+constexpr long SH_T = 1, SH_SRC16 = 2, SH_DST32 = 4, SH_ROWSUM = 8;
+
+__global__ __launch_bounds__(256) void shadow_multi_kernel(const ShadowDesc* __restrict__ table, const int* __restrict__ tile_start,
+                                                           int ndesc) {
+  __shared__ float tile[32][65];
+  __shared__ float rsum[32][9];
+  int lo = 0, hi = ndesc - 1;                         // last descriptor whose first tile is <= this workgroup's
+  const int me = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_start[mid] <= me) lo = mid; else hi = mid - 1;
+  }
+  const ShadowDesc d = table[lo];
+  const int t = me - tile_start[lo];
+  const int blk = (int)(d.flags >> 8);
+  const bool rowsum = d.flags & SH_ROWSUM;
+  const long ctiles = rowsum ? 1 : (d.cols + 63) / 64;
+  const long r0 = (t / ctiles) * 32, c0 = (t % ctiles) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 64 columns x 4 rows per pass
+  auto ld = [&](long r, long c) -> float {
+    float v = (d.flags & SH_SRC16) ? bf16_to_f32(((const bf16_t*)d.src)[r * d.src_ld + c]) : ((const float*)d.src)[r * d.src_ld + c];
+    if (d.scale) v *= d.scale[c];
+    return v;
+  };
+  auto rmap = [&](long r) -> long { return blk ? (r / blk) * 2 * blk + r % blk : r; };
+  if (rowsum) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (long c = tx; c < d.cols; c += 64)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long r = r0 + ty * 8 + i;
+        if (r < d.rows) acc[i] += bf16_to_f32(f32_to_bf16(ld(r, c)));
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float s_ = wave_sum(acc[i]);
+      const long r = r0 + ty * 8 + i;
+      if (tx == 0 && r < d.rows) ((float*)d.dst)[r] = s_;
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long r = r0 + ty + 4 * i, c = c0 + tx;
+    tile[ty + 4 * i][tx] = (r < d.rows && c < d.cols) ? ld(r, c) : 0.f;
+  }
+  __syncthreads();
+  if (!(d.flags & SH_T)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long r = r0 + ty + 4 * i, c = c0 + tx;
+      if (r < d.rows && c < d.cols) {
+        const long o = rmap(r) * d.dst_ld + c;
+        if (d.flags & SH_DST32) ((float*)d.dst)[o] = tile[ty + 4 * i][tx];
+        else ((bf16_t*)d.dst)[o] = f32_to_bf16(tile[ty + 4 * i][tx]);
+      }
+    }
+  } else {
+    const int rx = threadIdx.x & 31, cy = threadIdx.x >> 5;     // 32 source rows (contiguous in dst) x 8 source columns per pass
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long r = r0 + rx, c = c0 + cy + 8 * i;
+      if (r < d.rows && c < d.cols) {
+        const long o = c * d.dst_ld + rmap(r);
+        if (d.flags & SH_DST32) ((float*)d.dst)[o] = tile[rx][cy + 8 * i];
+        else ((bf16_t*)d.dst)[o] = f32_to_bf16(tile[rx][cy + 8 * i]);
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ctclip_shadow_multi(const void* table, const int* tile_start, int ndesc, int total_tiles, void* stream) {
+  if (ndesc <= 0 || total_tiles <= 0) return 0;
+  hipLaunchKernelGGL(shadow_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const ShadowDesc*)table,
+                     tile_start, ndesc);
+  CTCLIP_CHECK_LAUNCH();
+}

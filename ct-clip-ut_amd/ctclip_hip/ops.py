@@ -45,6 +45,122 @@ class ShadowCache:
             self._store[key] = ent
         return ent[1]
 
+    def get_set(self, key, params, make):
+        """The same for descriptor-driven shadows: `make()` -> ShadowSet is called once (and again if a parameter's storage
+        moved); afterwards a changed version only re-runs the copy kernel (PLAN.refresh) -- one launch for the whole model per
+        optimiser step -- and no tensor is re-created."""
+        ver = (_weight_epoch,) + tuple((p._version, p.data_ptr()) for p in params)
+        ent = self._store.get(key)
+        ptrs = tuple(p.data_ptr() for p in params)
+        if ent is None or ent[2] != ptrs:
+            with torch.no_grad():
+                s_ = make()
+            if ent is not None and ent[1] in PLAN.sets:
+                PLAN.sets.remove(ent[1])
+            PLAN.register(s_)
+            ent = [None, s_, ptrs]
+            self._store[key] = ent
+        if ent[0] != ver:
+            s_ = ent[1]
+            # already refilled by another module's refresh at this epoch, and none of OUR parameters was written since we last looked
+            covered = s_.fresh_epoch == ver[0] and ent[0] is not None and ent[0][1:] == ver[1:]
+            if not covered:
+                with torch.no_grad():
+                    PLAN.refresh(s_, ver[0])
+            ent[0] = ver
+        return ent[1].out
+
+
+class ShadowSet:
+    """The descriptor-driven shadows of one module (ctclip_shadow_multi, csrc/elementwise.hip): destination tensors that live as
+    long as the module and the table rows that (re)fill them from the f32 parameters.  `out` is what the module's kernels read."""
+
+    def __init__(self, device):
+        self.device = device
+        self.rows = []                       # [src, dst, rows, cols, src_ld, dst_ld, flags, scale]
+        self.keep = []                       # the tensors behind the raw pointers
+        self.out = {}
+        self.fresh_epoch = None              # weight epoch the destinations were last filled at
+        self._table = None
+
+    def zeros(self, *shape, dtype=torch.bfloat16):
+        t = torch.zeros(*shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def add(self, src, dst, *, transpose=False, blk=0, scale=None, rowsum=False):
+        """dst <- src ([rows, cols] view of an f32 parameter or a bf16 tensor; 1-D = one row) in the layout the flags select.
+        `dst` is a view whose pointer already includes any row / column offset; its row stride is the leading dimension."""
+        src = src.detach()
+        s2 = src if src.dim() == 2 else src.reshape(1, -1)
+        assert s2.stride(1) == 1 and (dst.dim() == 1 or dst.stride(-1) == 1)
+        rows, cols = s2.shape
+        flags = (1 if transpose else 0) | (2 if s2.dtype == torch.bfloat16 else 0) | (4 if dst.dtype == torch.float32 else 0) \
+            | (8 if rowsum else 0) | (int(blk) << 8)
+        dst_ld = dst.stride(0) if dst.dim() == 2 else (cols if not transpose else 1)
+        sc = scale.detach() if scale is not None else None
+        self.rows.append([s2.data_ptr(), dst.data_ptr(), rows, cols, s2.stride(0), dst_ld, flags, 0 if sc is None else sc.data_ptr()])
+        self.keep += [src, dst] + ([sc] if sc is not None else [])
+        self._table = None
+
+    def tiles(self):
+        return [((r[2] + 31) // 32) * (1 if r[6] & 8 else (r[3] + 63) // 64) for r in self.rows]
+
+
+class ShadowPlan:
+    """Every registered ShadowSet of the process.  refresh(set) brings a set's destinations up to date: after an optimiser step
+    (the weight epoch moved) the first caller refills ALL sets with one launch; a set whose own parameters were written in
+    place in between is refilled alone."""
+
+    def __init__(self):
+        self.sets = []
+        self.epoch_done = None
+        self._all = None
+
+    @staticmethod
+    def _device_table(sets):
+        rows = [r for s_ in sets for r in s_.rows]
+        tiles = [t for s_ in sets for t in s_.tiles()]
+        starts, acc = [], 0
+        for t in tiles:
+            starts.append(acc)
+            acc += t
+        dev = sets[0].device
+        return (torch.tensor(rows, dtype=torch.int64, device=dev), torch.tensor(starts, dtype=torch.int32, device=dev), len(rows), acc)
+
+    @staticmethod
+    def _launch(tab):
+        table, starts, n, total = tab
+        hip.shadow_multi(table, starts, n, total)
+
+    def register(self, s_):
+        self.sets.append(s_)
+        self._all = None
+
+    def refresh(self, s_, epoch):
+        """Fill s_'s destinations now.  The first call after the weight epoch moved fills EVERY registered set with one launch
+        (and marks them: `fresh_epoch`); later calls in the same epoch fill the one set."""
+        if self.epoch_done != epoch and len(self.sets) > 1:
+            if self._all is None:
+                by_dev = {}
+                for x in self.sets:
+                    by_dev.setdefault(x.device, []).append(x)
+                self._all = {d: self._device_table(v) for d, v in by_dev.items()}
+            for d, tab in self._all.items():
+                with torch.cuda.device(d):
+                    self._launch(tab)
+            self.epoch_done = epoch
+            for x in self.sets:
+                x.fresh_epoch = epoch
+            return
+        if s_._table is None:
+            s_._table = self._device_table([s_])
+        self._launch(s_._table)
+        s_.fresh_epoch = epoch
+
+
+PLAN = ShadowPlan()
+
 
 def pad8(n: int) -> int:
     return (n + 7) // 8 * 8

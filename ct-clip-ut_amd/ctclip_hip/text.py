@@ -265,7 +265,7 @@ def _layer_shadows(layer, heads, dh, dp):
     cache = layer.__dict__.setdefault("_ctclip_shadow", ops.ShadowCache())
     p = _layer_params(layer)
 
-    def build():
+    def build():                                      # head sizes that need zero rows per head: framework ops
         pad = lambda w: ops.pad_head_rows(w, heads, dh, dp)
         padb = lambda b: ops.pad_head_rows(b[:, None], heads, dh, dp)[:, 0]
         d = {
@@ -278,6 +278,23 @@ def _layer_shadows(layer, heads, dh, dp):
                  woT=d["wo"].t().contiguous())
         return d
 
+    def make():                                       # dh == dp (BERT-base: 64): one descriptor table (ctclip_shadow_multi)
+        inner, Hd, I = heads * dh, p[0].shape[1], p[10].shape[0]
+        S = ops.ShadowSet(p[0].device)
+        o = {"wqkv": S.zeros(3 * inner, Hd), "wqkvT": S.zeros(Hd, 3 * inner), "bqkv": S.zeros(3 * inner, dtype=F32),
+             "wao": S.zeros(Hd, inner), "waoT": S.zeros(inner, Hd), "wi": S.zeros(I, Hd), "wiT": S.zeros(Hd, I),
+             "wo": S.zeros(Hd, I), "woT": S.zeros(I, Hd), "inter": I}
+        for j, (w, b) in enumerate(((p[0], p[1]), (p[2], p[3]), (p[4], p[5]))):
+            S.add(w, o["wqkv"][j * inner:]); S.add(w, o["wqkvT"][:, j * inner:], transpose=True)
+            S.add(b, o["bqkv"][j * inner:])
+        S.add(p[6], o["wao"]); S.add(p[6], o["waoT"], transpose=True)
+        S.add(p[10], o["wi"]); S.add(p[10], o["wiT"], transpose=True)
+        S.add(p[12], o["wo"]); S.add(p[12], o["woT"], transpose=True)
+        S.out = o
+        return S
+
+    if dh == dp:
+        return cache.get_set("bert", p, make)
     return cache.get("bert", p, build)
 
 

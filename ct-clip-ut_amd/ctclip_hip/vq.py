@@ -46,7 +46,13 @@ class VectorQuantize(nn.Module):
 
     def _embed16(self):
         e = self._codebook.embed
-        return self._shadow.get("e16", (e,), lambda: e[0].to(BF16).contiguous())
+        def make():
+            S = ops.ShadowSet(e.device)
+            e16 = S.zeros(*e.shape[1:])
+            S.add(e[0], e16)
+            S.out = e16
+            return S
+        return self._shadow.get_set("e16", (e,), make)
 
     def forward(self, x, freeze_codebook=False):
         """x [b, n, d] -> (quantised [b,n,d] (straight-through), indices [b,n], commitment loss 0)."""

@@ -78,7 +78,13 @@ class CTCLIP(nn.Module):
         wv = self.to_visual_latent.weight
         if wv.shape[1] % 8 or wv.shape[0] % 8:
             raise ValueError("dim_image and dim_latent must be multiples of 8 for the bf16 MFMA path")
-        wv16 = self._shadow.get("wv", (wv,), lambda: wv.to(BF16).contiguous())
+        def make():                                   # bf16 shadow of the 294 912 -> 512 projection, refilled by ctclip_shadow_multi
+            S = ops.ShadowSet(wv.device)
+            w16 = S.zeros(*wv.shape)
+            S.add(wv, w16)
+            S.out = w16
+            return S
+        wv16 = self._shadow.get_set("wv", (wv,), make)
         image_latents = ops.VisualLatentFn.apply(image_tokens.to(F32), wv, wv16)              # :111-112,116
         text_latents = ops.LinearF32Fn.apply(text_output.to(F32), self.to_text_latent.weight, None, False)  # :115
         text_latents = ops.RowNormFn.apply(text_latents)                                      # :119

@@ -80,23 +80,25 @@ class FeedForward(nn.Sequential):
         w1, w2 = self[1].weight, self[4].weight
         I, Ip = self.inner, ops.pad64(self.inner)      # 1365 -> 1408: every K of the MLP is a whole number of 64-wide k-tiles
 
-        def build():
+        def make():
             # value rows 0..I-1 and gate rows I..2I-1 of the reference weight, each zero-padded to Ip and then interleaved
             # in 32-row blocks [val 32 | gate 32 | val 32 | ...] (ops.GEGLU_BLOCK): each wave's 64-column slab of the GEMM
             # tile then holds a value block and its gate block and the GEGLU is applied in the GEMM epilogue, straight from
-            # the accumulator registers (ctclip_gemm_bf16_geglu)
-            val = torch.zeros(Ip, self.dim, dtype=BF16, device=w1.device)
-            gate = torch.zeros(Ip, self.dim, dtype=BF16, device=w1.device)
-            val[:I] = w1[:I]
-            gate[:I] = w1[I:]
+            # the accumulator registers (ctclip_gemm_bf16_geglu).  Filled by ctclip_shadow_multi (pad rows / columns stay zero).
             blk = ops.GEGLU_BLOCK
-            w1p = torch.stack((val.view(Ip // blk, blk, self.dim), gate.view(Ip // blk, blk, self.dim)), dim=1).reshape(2 * Ip, self.dim)
-            w1p = w1p.contiguous()
-            w2p = torch.zeros(self.dim, Ip, dtype=BF16, device=w2.device)
-            w2p[:, :I] = w2
-            return {"w1": w1p, "w2": w2p, "w1T": w1p.t().contiguous(), "w2T": w2p.t().contiguous(), "inner": I, "inner_p": Ip}
+            S = ops.ShadowSet(w1.device)
+            w1p, w1T = S.zeros(2 * Ip, self.dim), S.zeros(self.dim, 2 * Ip)
+            w2p, w2T = S.zeros(self.dim, Ip), S.zeros(Ip, self.dim)
+            S.add(w1[:I], w1p, blk=blk)
+            S.add(w1[I:], w1p[blk:], blk=blk)
+            S.add(w1[:I], w1T, transpose=True, blk=blk)
+            S.add(w1[I:], w1T[:, blk:], transpose=True, blk=blk)
+            S.add(w2, w2p)
+            S.add(w2, w2T, transpose=True)
+            S.out = {"w1": w1p, "w2": w2p, "w1T": w1T, "w2T": w2T, "inner": I, "inner_p": Ip}
+            return S
 
-        return self._shadow.get("ff", (w1, w2), build)
+        return self._shadow.get_set("ff", (w1, w2), make)
 
     def forward(self, x, residual: bool = False):
         _need_cuda(x, "FeedForward")
@@ -174,11 +176,11 @@ class Attention(nn.Module):
         wq, wkv, wo, qs, ks = self.to_q.weight, self.to_kv.weight, self.to_out.weight, self.q_scale, self.k_scale
         gamma = self.norm.gamma
 
-        def build():
+        def build():                                  # head sizes that need zero rows per head (dh != dp): framework ops
             inner = H * dh
             k_w, v_w = wkv[:inner], wkv[inner:]
             pad = lambda w: ops.pad_head_rows(w, H, dh, dp)
-            scale_p = lambda s: torch.cat((s.detach().to(F32), s.new_zeros(dp - dh))) if dp != dh else s.detach().to(F32).clone()
+            scale_p = lambda s: torch.cat((s.detach().to(F32), s.new_zeros(dp - dh)))
             d = {
                 "wq": pad(wq).to(BF16).contiguous(),
                 "wkv": torch.cat((pad(k_w), pad(v_w)), 0).to(BF16).contiguous(),
@@ -187,17 +189,32 @@ class Attention(nn.Module):
             }
             # transposed copies of the (small) weights: dgrad then has the forward's k-major x k-major layout
             d.update(wqT=d["wq"].t().contiguous(), wkvT=d["wkv"].t().contiguous(), woutT=d["wout"].t().contiguous())
-            if dp == dh:
-                # the LayerNorm's gamma folded into the q projection (q = xhat (Wq gamma)^T, attention.py:140,142): the GEMM
-                # operand is the plain normalised row, which is then all the LayerNorm backward needs (ops.AttentionFn)
-                wqg = torch.empty(inner, self.dim, dtype=BF16, device=wq.device)
-                hip.patch_affine_fold(wq.detach(), None, gamma.detach(), None, wqg, None, inner, self.dim, self.dim)
-                d.update(wqg=wqg, wqgT=wqg.t().contiguous())
-                # one k-major operand [dim, inner + 2 inner] for the block's input gradient dx = [rstd dq | dkv] [Wqg ; Wkv]
-                # (ctclip_gemm_bf16_lnbwd), and the row sums of Wqg its LayerNorm-backward constants need
-                d.update(wcat=torch.cat((d["wqgT"], d["wkvT"]), 1).contiguous(), wbar=wqg.float().sum(1).contiguous())
             return d
 
+        def make():                                   # production head size: one descriptor table, no framework ops
+            inner, dim = H * dh, self.dim
+            S = ops.ShadowSet(wq.device)
+            o = {"wq": S.zeros(inner, dim), "wkv": S.zeros(2 * inner, dim), "wout": S.zeros(dim, inner),
+                 "wqT": S.zeros(dim, inner), "wkvT": S.zeros(dim, 2 * inner), "woutT": S.zeros(inner, dim),
+                 "q_scale": S.zeros(dp, dtype=F32), "k_scale": S.zeros(dp, dtype=F32),
+                 # the LayerNorm's gamma folded into the q projection (q = xhat (Wq gamma)^T, attention.py:140,142): the GEMM
+                 # operand is the plain normalised row, which is then all the LayerNorm backward needs (ops.AttentionFn);
+                 # wcat = [Wqg^T | Wkv^T] is the one k-major operand of the block's input gradient
+                 # dx = [rstd dq | dkv] [Wqg ; Wkv] (ctclip_gemm_bf16_lnbwd), wbar the row sums of Wqg its row constants need
+                 "wqg": S.zeros(inner, dim), "wqgT": S.zeros(dim, inner), "wcat": S.zeros(dim, 3 * inner),
+                 "wbar": S.zeros(inner, dtype=F32)}
+            S.add(wq, o["wq"]); S.add(wq, o["wqT"], transpose=True)
+            S.add(wkv, o["wkv"]); S.add(wkv, o["wkvT"], transpose=True)
+            S.add(wo, o["wout"]); S.add(wo, o["woutT"], transpose=True)
+            S.add(qs, o["q_scale"]); S.add(ks, o["k_scale"])
+            S.add(wq, o["wqg"], scale=gamma); S.add(wq, o["wqgT"], transpose=True, scale=gamma)
+            S.add(wq, o["wcat"], transpose=True, scale=gamma); S.add(wkv, o["wcat"][:, inner:], transpose=True)
+            S.add(wq, o["wbar"], rowsum=True, scale=gamma)
+            S.out = o
+            return S
+
+        if dp == dh:
+            return self._shadow.get_set("attn", (wq, wkv, wo, qs, ks, gamma), make)
         return self._shadow.get("attn", (wq, wkv, wo, qs, ks, gamma), build)
 
     def forward(self, x, mask=None, context=None, attn_bias=None, residual: bool = False, x16=None):

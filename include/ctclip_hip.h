@@ -339,6 +339,15 @@ int ctclip_bert_embed_bwd(const long* ids, const long* token_type, const float* 
 int ctclip_ingest_volume(const void* raw, int raw_is_i16, int H, int W, int D, float slope, float intercept, int rD, int rH,
                          int rW, int oD, int oH, int oW, float pad_value, void* out, int out_bf16, void* stream);
 
+/* ---- weight shadows (host side: ctclip_hip/ops.py ShadowPlan): the bf16 / transposed / zero-padded / block-interleaved /
+ * gamma-scaled kernel-layout copies of the f32 master weights, all in ONE launch per optimiser step (the reference keeps one
+ * fp16 autocast copy per nn.Linear call: torch.autocast in src/utils/CTClipTrainer.py:186-189).  table: ndesc descriptors of 8
+ * 64-bit words {src, dst, rows, cols, src_ld, dst_ld, flags, scale}: flags bit 0 transposed destination, bit 1 bf16 source, bit 2
+ * f32 destination, bit 3 row sums (dst[r] = sum_c bf16(src[r][c] scale[c])), bits 8.. blk (destination row r ->
+ * (r / blk) 2 blk + r % blk; 0 = r); scale: per-column f32 factor or NULL.  tile_start[d]: first 32 x 64 tile of descriptor d,
+ * total_tiles: their sum (row sums take one tile per 32 rows). */
+int ctclip_shadow_multi(const void* table, const int* tile_start, int ndesc, int total_tiles, void* stream);
+
 /* ---- diagnostic: register-resident MFMA 32x32x16 bf16 loop, blocks x 512 threads x iters x 16 MFMAs per wave; times
  * what the matrix pipes sustain at the clock the part holds under load (no reference counterpart) ---- */
 int ctclip_probe_mfma(float* out, int blocks, int iters, void* stream);
