@@ -552,9 +552,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("CTCLIP_BENCH_BATCH", 88)),
-                    help="pairs per GPU (BASELINE configs[1]: sized to the 288 GB of HBM; 88 pairs peak at ~235 GiB; measured "
-                         "pairs/s at 64 / 80 / 96: profiles/r03_batch_sweep.txt)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("CTCLIP_BENCH_BATCH", 96)),
+                    help="pairs per GPU (BASELINE configs[1]: sized to the 288 GB of HBM; 96 pairs peak at ~234 GiB; measured "
+                         "pairs/s at 88 / 96 / 104: profiles/r04_batch_sweep.txt)")
     ap.add_argument("--text-len", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-attribution", action="store_true", help="skip the BASELINE configs[4] measurement (occlusion + IG)")

@@ -646,8 +646,6 @@ int ctclip_attn_fwd_dropout(const void* q, const void* k, const void* v, void* o
   {
     const int ew = ctclip_attn_ws_fwd(a, dhead, (hipStream_t)stream);  // long rows with a shared bias: a wave per sequence
     if (ew >= 0) return ew;
-    const int e = ctclip_attn_sp_fwd(a, dhead, (hipStream_t)stream);   // ... or the sequence-persistent kernels
-    if (e >= 0) return e;
   }
   const int nw = waves_for(n, dhead);
   const size_t lds1h = (size_t)a.n_pad * dhead * 2;
@@ -695,8 +693,6 @@ int ctclip_attn_bwd_dropout(const void* q, const void* k, const void* v, const v
   {
     const int ew = ctclip_attn_ws_bwd(a, dhead, (hipStream_t)stream);  // a wave per sequence (attention_ws.hip)
     if (ew >= 0) return ew;
-    const int e = ctclip_attn_sp_bwd(a, dhead, (hipStream_t)stream);
-    if (e >= 0) return e;
   }
   static const bool no_small = CTCLIP_KNOB("CTCLIP_ATTN_NO_SMALL") != nullptr;
   if (dhead == 32 && n <= 32 && !a.dbias_dense && !a.dbias_table && !a.drop && !no_small) {

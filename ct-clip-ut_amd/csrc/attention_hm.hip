@@ -36,12 +36,6 @@
 #ifndef HM_STAMPS
 #define HM_STAMPS 0                   // diagnostic build: per-wave cycle totals of the forward's phases (tools/bench_attn_hm.py STAMPS=1)
 #endif
-#ifndef HM_BIAS_C
-#define HM_BIAS_C 1                   // forward: bias tile through the score MFMA's C operand (0: the f16 identity product)
-#endif
-#ifndef HM_ABL
-#define HM_ABL 0                      // timing-only ablations of the forward (tools/build_variant.sh); 0 in every product build
-#endif
 
 namespace {
 
@@ -184,14 +178,8 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
   char* vimg = smem + (size_t)(HAS_BIAS ? QB * T : 0) * 2048 + (size_t)w * 4096;   // wave-private: 2 x [32 keys][32 d] bf16
   __shared__ int seq_counter;
   if (tid == 0) seq_counter = seq0;
-#if HM_BIAS_C
   if (HAS_BIAS) fill_bias_c(bias_l, a.bias + (long)head * a.n * a.n, a.n, q0, nqb, QB, T, tid, NW * 64);
-#else
-  if (HAS_BIAS) fill_bias<true>(bias_l, a.bias + (long)head * a.n * a.n, a.n, q0, nqb, QB, T, tid, NW * 64);
-#endif
   __syncthreads();
-  half8 idf[2];
-  identity_frags(idf, r, half);
   const f32x16 zero16 = splat16(0.f);
   const int crow = lane >> 2, ccol = lane & 3;                     // 16-byte piece of a V tile: rows crow, crow + 16
   const uint32_t koff = (uint32_t)(r * 32 + 8 * half);
@@ -261,34 +249,18 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
 
     auto tile = [&](int slot, int t) {
       char* vi = vimg + (t & 1) * 2048;
-#if !(HM_ABL & 16)
       *(u32x4*)(vi + vst) = vr[slot][0];
       *(u32x4*)(vi + vst + 1024) = vr[slot][1];
-#endif
       const bf16x8 k0 = kr[slot][0], k1 = kr[slot][1];
-#if HM_ABL & 16
-      const bf16x8 vt0 = k0, vt1 = k1;
-#else
       const bf16x8 vt0 = tr_frag<32>(vi, 0, 0, 0, lane), vt1 = tr_frag<32>(vi, 0, 1, 0, lane);
-#endif
       f32x16 S[QB];
-#if HM_BIAS_C
-      if (HAS_BIAS && !(HM_ABL & 4)) {
+      if (HAS_BIAS) {
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
           const half8 c0 = bias_l[((b * T + t) * 2 + 0) * 64 + lane], c1 = bias_l[((b * T + t) * 2 + 1) * 64 + lane];
 #pragma unroll
           for (int j = 0; j < 8; ++j) { S[b][j] = (float)c0[j]; S[b][8 + j] = (float)c1[j]; }
         }
-#pragma unroll
-        for (int b = 0; b < QB; ++b) S[b] = mfma32(k0, qf[b][0], S[b]);
-      } else
-#endif
-      if (HAS_BIAS && !(HM_ABL & 4)) {
-#pragma unroll
-        for (int b = 0; b < QB; ++b) S[b] = mfma32h(bias_l[((b * T + t) * 2 + 0) * 64 + lane], idf[0], zero16);
-#pragma unroll
-        for (int b = 0; b < QB; ++b) S[b] = mfma32h(bias_l[((b * T + t) * 2 + 1) * 64 + lane], idf[1], S[b]);
 #pragma unroll
         for (int b = 0; b < QB; ++b) S[b] = mfma32(k0, qf[b][0], S[b]);
       } else {
@@ -301,12 +273,10 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
       // Request this slot's next tile AFTER the score MFMAs have read it (requested before them, the compiler parks k1 in
       // spare registers early -- a copy that waits for the OTHER slot's load, one tile ahead of its use).  UNCONDITIONAL:
       // behind a branch the wait-count bookkeeping no longer knows how many loads are in flight and waits for all of them.
-#if !(HM_ABL & 2)
       {
         const bool cur = t + 2 < T;                                // else: tile `slot` of the NEXT sequence lives in this slot
         request(slot, cur ? base : nbase, cur ? t + 2 : (slot < T ? slot : 0));
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int b = 0; b < QB; ++b) {
@@ -314,11 +284,7 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
           float l0 = 0.f, l1 = 0.f;
 #pragma unroll
           for (int i = 0; i < 16; i += 2) {
-#if HM_ABL & 1
-            const float e0 = S[b][i], e1 = S[b][i + 1];
-#else
             const float e0 = exp2_fast(S[b][i]), e1 = exp2_fast(S[b][i + 1]);
-#endif
             S[b][i] = e0; S[b][i + 1] = e1;
             l0 += e0; l1 += e1;
           }
@@ -344,12 +310,8 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_fwd_kernel(HmArgs a) {
           }
         }
         const bf16x8 p0 = acc_frag(S[b], 0), p1 = acc_frag(S[b], 1);
-#if HM_ABL & 8
-        O[b][0] += (float)p0[0] + (float)p1[0] + (float)vt0[0] + (float)vt1[0];
-#else
         O[b] = mfma32(vt0, p0, O[b]);
         O[b] = mfma32(vt1, p1, O[b]);
-#endif
       }
     };
 #if HM_STAMPS

@@ -1,13 +1,17 @@
-// "Wave owns the sequence" fused attention for gfx950: the CT-ViT spatial shape (reference src/utils/attention.py:155-180,
-// n = 576 tokens per frame, d_head = 32, one [heads, n, n] relative-position bias shared by EVERY sequence).
+// "Wave owns the sequence" fused attention for gfx950: spatial attention rows with one [heads, n, n] relative-position bias
+// shared by EVERY sequence (reference src/utils/attention.py:155-180), operands in the ROW-MAJOR [token][heads * 32] layout.
 //
-// attention_sp.hip keeps the bias tiles of a (head, 32-row query block) in registers by splitting the n/32 key tiles of
-// every sequence over the eight waves of a workgroup -- and pays for it with a barrier, a partial-result exchange through
-// LDS and a combine per sequence: measured ~6700 cycles per (sequence, query block) for ~600 cycles of matrix work and
-// ~1200 of softmax arithmetic, because all eight waves walk one short dependency chain in lock-step.
-// Here a workgroup still owns one (head, 32-row query block) for a chunk of sequences, but
+// WHO REACHES THIS FILE.  The CT-CLIP training step does not: its spatial attention (n = 576 or 256, 8 heads of 32) runs on the
+// head-major kernels of attention_hm.hip (ops.py: attn_head_major_ok).  ctclip_attn_fwd / _bwd land here for the spatial shapes
+// attention_hm.hip refuses: 21..24 key tiles per row (a non-square patch grid such as 24 x 28), an odd number of heads, or a
+// caller that needs the row-major operands.  Shorter rows (temporal attention, n = 24), key masks and dropout (BERT) use the
+// per-sequence kernels of attention.hip.  (Round 1's sequence-persistent form, attention_sp.hip, took exactly the shapes this
+// file takes and lost to it 2898 vs 1762 us; it was unreachable in a product build and is gone -- DESIGN.md section 4.4 keeps
+// its measurements.)
+//
+// A workgroup owns one (head, 32-row query block) for a chunk of sequences:
 //   * the bias tiles live in LDS, already in accumulator layout (tile t, register group j, lane l -> one float4), so a
-//     wave initialises the score accumulator with four conflict-free ds_read_b128 and the bias still enters the score MFMA
+//     wave initialises the score accumulator with four conflict-free ds_read_b128 and the bias enters the score MFMA
 //     as its C operand -- no VALU instruction;
 //   * every wave takes WHOLE SEQUENCES of the chunk (wave w: seq0 + w, seq0 + w + 8, ...) and runs a flash-style loop over
 //     the n/32 key tiles by itself: K tiles come straight from global memory as MFMA operands, V tiles go through a
@@ -15,7 +19,7 @@
 //     no barrier, no exchange, no combine after the bias fill;
 //   * K/V of tile t + 2 are requested while tile t is computed.
 // The price: each sequence's K/V is read once per query block (n/32 times) instead of once -- from L2, not from HBM.
-// Eligible: d_head 32, n % 32 == 0, n / 32 <= 24, no key mask, no dropout.
+// Eligible: d_head 32, n % 32 == 0, 4 <= n / 32 <= 24, no key mask, no dropout.
 #include "attn_common.h"
 
 namespace {
@@ -700,12 +704,12 @@ int ws_bwd_launch(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// -1: shape not eligible, the caller falls back to attention_sp.hip / attention.hip
+// -1: shape not eligible, the caller falls back to attention.hip
 int ctclip_attn_ws_fwd(const CtclipAttnArgs& a, int dhead, hipStream_t st) {
   if (!ws_shape_ok(a, dhead)) return -1;
   static const int qb = [] { const char* e = CTCLIP_KNOB("CTCLIP_ATTN_WS_QB"); return e ? atoi(e) : 2; }();
   // measured at 1536 x 8 x 576 x 32 (same box): QB 1 / 16 waves 2369 us (L2-bound), QB 2 / 8 waves 1762, QB 3 / 8 waves 1734,
-  // QB 2 / 12 waves 1820 (attention_sp.hip: 2898).  At QB = 2 the kernel issues 122 VALU instructions per score tile and
+  // QB 2 / 12 waves 1820 (round 1's sequence-persistent kernels: 2898).  At QB = 2 the kernel issues 122 VALU instructions per score tile and
   // the VALU is busy 62 % of the time (rocprofv3 SQ counters, profiles/r02_attention_pmc.txt): softmax-arithmetic bound.
 #ifdef CTCLIP_TUNING_KNOBS
   if (qb == 1) return ws_fwd_launch<1, 16, 2>(a, st);

@@ -1,4 +1,4 @@
-// Shared pieces of the fused attention kernels (attention.hip, attention_sp.hip): argument block, the swizzled
+// Shared pieces of the fused attention kernels (attention.hip, attention_ws.hip, attention_hm.hip): argument block, the swizzled
 // [row][D] LDS image and the MFMA fragment readers.  gfx950 only.
 #pragma once
 #include "common.h"
@@ -28,12 +28,9 @@ struct CtclipAttnArgs {
 };
 typedef CtclipAttnArgs AttnArgs;
 
-// sequence-persistent kernels for long rows with a shared bias (attention_sp.hip); return -1 when the shape is not
+// wave-owns-the-sequence kernels for long rows with a shared bias (attention_ws.hip); return -1 when the shape is not
 // eligible and the caller must use the per-sequence kernels of attention.hip.
-int ctclip_attn_sp_fwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
-// wave-owns-the-sequence kernels (attention_ws.hip): same shapes, tried first; -1 = not eligible
 int ctclip_attn_ws_fwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
-int ctclip_attn_sp_bwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
 int ctclip_attn_ws_bwd(const CtclipAttnArgs& a, int dhead, hipStream_t st);
 
 namespace {

@@ -4,7 +4,6 @@
 Forward = tubelet patch-embed kernel chain -> 4 spatial transformer layers (576-token sequences, relative
 position bias) -> 4 temporal layers (24-token sequences) -> cosine-sim VQ; all HIP (see ctclip_hip.ops).
 """
-import os
 from pathlib import Path
 
 import torch
@@ -96,7 +95,7 @@ class CTViT(nn.Module):
         attn_bias = self.spatial_rel_pos_bias.lookup(h, w, device=tokens.device)
         x = tokens.reshape(b * t, h * w, d)
         sp, tp = self.enc_spatial_transformer, self.enc_temporal_transformer
-        if _hooked(sp) or _hooked(tp) or os.environ.get("CTCLIP_NO_LN_SWAP"):
+        if _hooked(sp) or _hooked(tp):
             # someone watches a transformer's output: keep the reference's layouts and re-order in separate passes
             x = sp(x, attn_bias=attn_bias, video_shape=video_shape)
             x = ops.SwapMiddleFn.apply(x.reshape(b, t, h * w, d))                # (b t)(h w) -> (b h w) t

@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out
 mkdir -p $OUT/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
 REPO=$OLDPWD
-STEPS=${STEPS:-10}; WARM=${WARM:-3}; BATCH=${BATCH:-88}
+STEPS=${STEPS:-10}; WARM=${WARM:-3}; BATCH=${BATCH:-96}
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/stats -o stats -- python3 $REPO/bench.py --lean --batch $BATCH --steps $STEPS --warmup $WARM > $OUT/${TAG}_bench_under_profiler.json 2> $OUT/${TAG}_stats.err
 python3 $REPO/tools/prof_summary.py $(find $OUT/prof_$TAG/stats -name '*kernel_stats.csv' | head -1) $((STEPS + WARM + 2)) $OUT/${TAG}_default_bench_b${BATCH}_kernel_stats.csv > /dev/null
 if [ "${PMC:-1}" = "1" ]; then
