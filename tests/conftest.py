@@ -12,8 +12,11 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-# widen the dispatch gate of the pipelined GEMM so its ragged / split-K / transposed-operand paths are exercised
-os.environ.setdefault("CTCLIP_GEMM_V2_ALL", "1")
+# widen the dispatch gate of the pipelined GEMM so its ragged / split-K / transposed-operand paths are exercised.
+# CTCLIP_TEST_PRODUCT_GATES=1 leaves the gates as a training run has them (the model / production tests are run that way once
+# per round: profiles/r04_tests_product_gates.txt)
+if not os.environ.get("CTCLIP_TEST_PRODUCT_GATES"):
+    os.environ.setdefault("CTCLIP_GEMM_V2_ALL", "1")
 
 
 def pytest_configure(config):
