@@ -817,7 +817,7 @@ class FeedForwardFn(Function):
         # (include/ctclip_hip.h, ctclip_gemm_bf16_ffln): the product above also leaves the row sums of d(pre) the LayerNorm
         # backward is made of, the FF1 data gradient finishes dx, d(gamma), d(beta) in its epilogue -- d(n2) never exists
         tiles = ((M + 255) // 256) * ((Ip + 255) // 256)
-        fused_ln = "wbar" in sh and dim % 64 == 0 and M * dim < 2 ** 31 and (tiles >= 192 or (_V2_ALL and tiles >= 4))
+        fused_ln = "wbar" in sh and "w1T" in sh and dim % 64 == 0 and M * dim < 2 ** 31 and (tiles >= 192 or (_V2_ALL and tiles >= 4))
         if fused_ln:
             nslab, ldrp = Ip // 64, (M + 15) // 16 * 16
             rowpart = _scratch("ff_rowpart", nslab * 3 * ldrp, dy.device)
@@ -840,8 +840,8 @@ class FeedForwardFn(Function):
         if fused_ln:
             c12 = _scratch("ff_c12", 2 * M, dy.device)
             colpart = _scratch("ff_colpart", (M + 255) // 256 * 2 * 2 * dim, dy.device)
-            w1 = sh["w1"]
-            hip.gemm_bf16_ffln(dh, w1, dx, dx16, M, dim, 2 * Ip, dh.stride(0), w1.stride(0), ln_w.detach(), x2, mean, rstd, rowpart,
+            w1T = sh["w1T"]                              # [dim, 2 Ip]: the k-major operand of d(n2) = d(h) W1
+            hip.gemm_bf16_ffln(dh, w1T, dx, dx16, M, dim, 2 * Ip, dh.stride(0), w1T.stride(0), ln_w.detach(), x2, mean, rstd, rowpart,
                                nslab, dy2 if ctx.residual else None, c12, colpart, glw, glb)
         else:
             hip.layernorm_bwd_bf16(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, None, dx, dx16, glw, glb, M, dim)
