@@ -128,17 +128,8 @@ def gemm_work_fns():
     def lnbwd(A, B, dx, dx16, M, N, K, *rest):       # [rstd dq | dk | dv] [Wqg ; Wkv] with the LayerNorm backward in the epilogue
         return {"flops": 2.0 * M * N * K, "tag": "attn_proj",
                 "bytes": 2.0 * (M * K + N * K) + M * N * (4.0 + 2.0 + 4.0) + (2.0 * M * N if dx16 is not None else 0.0)}
-
-    def geglu_bwd_rows(dY, W, H, M, inner, K, *rest):          # the same product that also leaves the LayerNorm backward's row sums
-        return {"flops": 2.0 * M * _unpad(inner) * K, "bytes": 2.0 * (M * K + inner * K) + 2.0 * M * 4 * inner + 12.0 * M * (inner // 64)}
-
-    def ffln(dH, W1, dx, dx16, M, N, K, lda, ldb, gamma, x, mean, rstd, rowpart, nslab, dres, *rest):
-        # FF1 data gradient with the block's LayerNorm backward in its epilogue (x and the residual gradient read, dx written as
-        # f32 + bf16); the event pair also covers the row-constant and column-sum kernels of the entry point
-        return {"flops": 2.0 * M * N * _unpad(K),
-                "bytes": 2.0 * (M * K + N * K) + M * N * (4.0 + 4.0 + 2.0) + (4.0 * M * N if dres is not None else 0.0) + 12.0 * M * nslab}
     return {"gemm_bf16": plain, "gemm_bf16_geglu": geglu, "gemm_bf16_geglu_bwd": geglu_bwd, "gemm_bf16_headmajor": headmajor,
-            "gemm_bf16_lnbwd": lnbwd, "gemm_bf16_geglu_bwd_rows": geglu_bwd_rows, "gemm_bf16_ffln": ffln}
+            "gemm_bf16_lnbwd": lnbwd}
 
 
 def other_work_fns():

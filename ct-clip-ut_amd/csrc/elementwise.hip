@@ -498,7 +498,7 @@ int ctclip_dropout_bwd(const float* g, float* d, void* d_bf16, long n, float p, 
 //   map(r) = r, or with blk > 0  (r / blk) * 2 blk + r % blk     (the [val blk | gate blk | ...] interleave of the GEGLU weight:
 //                                                                  the gate half's dst pointer starts blk rows / columns in)
 // multiplied by scale[c] when a column scale is given (a LayerNorm's gamma folded into the projection behind it), as bf16 or
-// f32; ROWSUM instead writes dst[map(r)] = sum_c bf16(src[r][c] scale[c]) (f32).  A workgroup takes one 32 x 64 tile; tile_start[d] is
+// f32; ROWSUM instead writes dst[r] = sum_c bf16(src[r][c] scale[c]) (f32).  A workgroup takes one 32 x 64 tile; tile_start[d] is
 // the first tile of descriptor d.
 namespace {
 struct ShadowDesc { const void* src; void* dst; long rows, cols, src_ld, dst_ld, flags; const float* scale; };
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void shadow_multi_kernel(const ShadowDesc* __r
     for (int i = 0; i < 8; ++i) {
       const float s_ = wave_sum(acc[i]);
       const long r = r0 + ty * 8 + i;
-      if (tx == 0 && r < d.rows) ((float*)d.dst)[rmap(r)] = s_;
+      if (tx == 0 && r < d.rows) ((float*)d.dst)[r] = s_;
     }
     return;
   }

@@ -434,14 +434,6 @@ int ctclip_gemm5_launch(const void* A, const void* B, void* C, const float* bias
 int ctclip_gemm3_launch_ln(const void* A, const void* B, float* C, void* C16, const float* resid, int M, int N, int K, long lda,
                            long ldb, long ldc, long ldc16, long ldr, const void* xhat, long ldx, const float* c1, const float* c2,
                            hipStream_t st);
-int ctclip_gemm3_launch_ff6(const void* dY, const void* W2T, void* H, int M, int inner, int K, long lddy, long ldw, long ldh,
-                            const float* wbar, const float* bfold, float* rowpart, long ldrp, hipStream_t st);
-int ctclip_gemm3_launch_ff5(const void* dH, const void* W1, float* dx, void* dx16, const float* dres, int M, int N, int K, long lda,
-                            long ldb, const float* gamma, const float* x, const float* mean, const float* rstd, const float* c1,
-                            const float* c2, float* colpart, hipStream_t st);
-extern "C" int ctclip_ff_rowconst(const float* rowpart, long ldrp, int nslab, const float* rstd, int dim, float* c1, float* c2, int rows,
-                                  void* stream);
-extern "C" int ctclip_colsum_accum(const void* x, int x_is_bf16, long rows, int cols, long ld, float* out, float* partials, void* stream);
 int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
                         float alpha, float* part, hipStream_t st);
 int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
@@ -659,45 +651,6 @@ int ctclip_gemm_bf16_geglu_bwd(const void* dY, const void* W2T, void* H_dH, void
   if (int e = ctclip_gemm_bf16(dY, W2T, dG_scratch, nullptr, nullptr, M, inner, K, lddy, ldw, lddg, 0, 1, 1, 0, 1, 0, 1.0f, 0, nullptr, 0, stream))
     return e;
   return ctclip_geglu_bwd(dG_scratch, H_dH, H_dH, M, inner, 32, lddg, ldh, stream);
-}
-
-// The FF block's backward pair with its LayerNorm backward inside (include/ctclip_hip.h).  Always the 256 x 256 LDS-DMA kernel of
-// gemm3.hip: these epilogues exist in no other form.
-int ctclip_gemm_bf16_geglu_bwd_rows(const void* dY, const void* W2T, void* H_dH, int M, int inner, int K, long lddy, long ldw,
-                                    long ldh, const float* wbar, const float* bfold, float* rowpart, void* stream) {
-  if (M <= 0 || inner <= 0) return 0;
-  if ((inner & 63) || K <= 0 || (K % 32) || !wbar || !rowpart || (ldh & 7) || (((uintptr_t)H_dH) & 15) ||
-      ((((uintptr_t)wbar) | ((uintptr_t)bfold) | ((uintptr_t)rowpart)) & 15) || bad_layout(dY, lddy, K, true) ||
-      bad_layout(W2T, ldw, K, true))
-    return (int)hipErrorInvalidValue;
-  return ctclip_gemm3_launch_ff6(dY, W2T, H_dH, M, inner, K, lddy, ldw, ldh, wbar, bfold, rowpart, ((long)M + 15) / 16 * 16,
-                                 (hipStream_t)stream);
-}
-
-int ctclip_gemm_bf16_ffln(const void* dH, const void* W1, float* dx, void* dx_bf16, int M, int N, int K, long lda, long ldb,
-                          const float* gamma, const float* x, const float* mean, const float* rstd, const float* rowpart, int nslab,
-                          const float* dres, float* c12, float* colpart, float* dgamma, float* dbeta, float* partials,
-                          void* stream) {
-  if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if ((K % 32) || (N & 3) || (long)M * N >= (1L << 31) || !gamma || !x || !mean || !rstd || !rowpart || nslab <= 0 || !c12 ||
-      !colpart || !dx || !partials ||
-      ((((uintptr_t)dx) | ((uintptr_t)x) | ((uintptr_t)dres) | ((uintptr_t)gamma) | ((uintptr_t)colpart)) & 15) ||
-      (((uintptr_t)dx_bf16) & 7) || bad_layout(dH, lda, K, true) || bad_layout(W1, ldb, K, true))
-    return (int)hipErrorInvalidValue;
-  const long ldrp = ((long)M + 15) / 16 * 16;
-  float* c1 = c12;
-  float* c2 = c12 + M;
-  if (int e = ctclip_ff_rowconst(rowpart, ldrp, nslab, rstd, N, c1, c2, M, stream)) return e;
-  if (int e = ctclip_gemm3_launch_ff5(dH, W1, dx, dx_bf16, dres, M, N, K, lda, ldb, gamma, x, mean, rstd, c1, c2, colpart,
-                                      (hipStream_t)stream))
-    return e;
-  // colpart: [slot = 128-row group][{d(beta), d(gamma)}][N]; every slot of the ceil(M / 256) row tiles was written
-  const long nslots = ((long)M + 255) / 256 * 2;
-  if (dbeta)
-    if (int e = ctclip_colsum_accum(colpart, 0, nslots, N, 2L * N, dbeta, partials, stream)) return e;
-  if (dgamma)
-    if (int e = ctclip_colsum_accum(colpart + N, 0, nslots, N, 2L * N, dgamma, partials, stream)) return e;
-  return 0;
 }
 
 }  // extern "C"

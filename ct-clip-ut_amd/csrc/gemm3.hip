@@ -75,10 +75,9 @@ __device__ long g_stamp_cap = 0;
 //              loops running side by side reach ~50 % of the matrix pipe where one 256 x 256 loop reaches ~64 %.
 // EPI selects the epilogue at compile time (one kernel per form keeps the two-workgroup shape inside 128 registers):
 //   0 plain -> bf16   1 plain -> f32   (both: alpha, bias, residual, erf-GELU when g.act == 1)   2 FF1 + GEGLU   3 FF2 dgrad + GEGLU backward
-//   4 f32 with a LayerNorm backward whose row constants the caller has   5 / 6 the FF block's pair (gemm_tile.h): 256 x 256 only
 template <int TBN, int EPI>
 __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g) {
-  constexpr bool F32OUT = EPI == 1 || EPI == 4 || EPI == 5;     // identity N-fragment rows: a lane holds 4 contiguous f32 columns
+  constexpr bool F32OUT = EPI == 1 || EPI == 4;     // identity N-fragment rows: a lane holds 4 contiguous f32 columns
   constexpr int WN = TBN / 64, WM = 8 / WN;            // wave grid: 2 x 4 or 4 x 2
   constexpr int IM = BM / WM / 16, JN = 4;             // MFMA tiles per wave: 8 x 4 or 4 x 4 (the slab is always 64 columns)
   constexpr int TNS = (TBN == 256) ? G3_NS256 : 3;     // ring stages
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
   }
   counted = g.direct && erow0 + BM <= g.M && ecol0 + TBN <= g.N && nk >= TNS - 1;
   // this wave's 64-column slab; the two-workgroup shape has 128 registers: no second buffer for the epilogue's reads
-  epilogue_slab<EPI, IM, JN, 0, (TBN == 256)>(g, acc, erow0 + wm * (IM * 16), ecol0 + wn * 64, lane);
+  epilogue_slab<EPI, IM, JN, 0, TBN == 256>(g, acc, erow0 + wm * (IM * 16), ecol0 + wn * 64, lane);
   G3_STAMP(6);                                        // every store of wave 0 issued
 #ifdef CTCLIP_G3_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and drained
@@ -442,7 +441,7 @@ int g3_launch(g3::Args& g, int epi, int c_fp32, hipStream_t st) {
   using namespace g3;
   const int M = g.M, N = g.N, K = g.K;
   static const int forced = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM3_BN"); return e ? atoi(e) : 0; }();
-  const int bn = epi >= 5 ? 256 : (forced == 128 || forced == 256) ? forced : ((c_fp32 && K <= 256) ? 128 : 256);
+  const int bn = (forced == 128 || forced == 256) ? forced : ((c_fp32 && K <= 256) ? 128 : 256);
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + bn - 1) / bn;
 #define G3_LAUNCH(BN_, EPI_, LDS_)                                                                                        \
   do {                                                                                                                    \
@@ -473,10 +472,7 @@ int g3_launch(g3::Args& g, int epi, int c_fp32, hipStream_t st) {
   else if (epi == 1) G3_SHAPES(1);
   else if (epi == 2) G3_SHAPES(2);
   else if (epi == 3) G3_SHAPES(3);
-  else if (epi == 4) G3_SHAPES(4);
-  else if (bn != 256) return (int)hipErrorInvalidValue;
-  else if (epi == 5) G3_LAUNCH(256, 5, (size_t)G3_NS256 * (SUB + 256 * BK * 2));
-  else { g.vb_lds = (uint32_t)((size_t)G3_NS256 * (SUB + 256 * BK * 2)); G3_LAUNCH(256, 6, (size_t)G3_NS256 * (SUB + 256 * BK * 2) + 8 * 512); }
+  else G3_SHAPES(4);
 #undef G3_SHAPES
 #undef G3_LAUNCH
   return (int)hipGetLastError();
@@ -543,31 +539,6 @@ int ctclip_gemm3_launch_ln(const void* A, const void* B, float* C, void* C16, co
   g.alpha = 1.0f; g.direct = 1;
   g.xhat = (const bf16_t*)xhat; g.ldx = ldx; g.c1 = c1; g.c2 = c2; g.C16 = (bf16_t*)C16; g.ldc16 = ldc16;
   return g3_launch(g, 4, 1, st);
-}
-
-// The FF block's backward pair (gemm_tile.h, EPI 6 and EPI 5; gemm.hip checks the arguments).
-// EPI 6: h <- d(h) = GEGLU backward of dY W2T (as EPI 3) + rowpart[slab][row] = the two row sums of the slab.
-int ctclip_gemm3_launch_ff6(const void* dY, const void* W2T, void* H, int M, int inner, int K, long lddy, long ldw, long ldh,
-                            const float* wbar, const float* bfold, float* rowpart, long ldrp, hipStream_t st) {
-  using namespace g3;
-  Args g{};
-  g.A = (const bf16_t*)dY; g.B = (const bf16_t*)W2T; g.G = (bf16_t*)H; g.ldg = ldh;
-  g.lda = lddy; g.ldb = ldw; g.M = M; g.N = inner; g.K = K; g.alpha = 1.0f; g.direct = 1;
-  g.wbar = wbar; g.bfold = bfold; g.rowpart = rowpart; g.ldrp = ldrp;
-  return g3_launch(g, 6, 0, st);
-}
-
-// EPI 5: dx = rstd gamma (dH W1) - c1 - xhat c2 + dres with xhat = (x - mean) rstd; colpart = per-128-row column sums.
-int ctclip_gemm3_launch_ff5(const void* dH, const void* W1, float* dx, void* dx16, const float* dres, int M, int N, int K, long lda,
-                            long ldb, const float* gamma, const float* x, const float* mean, const float* rstd, const float* c1,
-                            const float* c2, float* colpart, hipStream_t st) {
-  using namespace g3;
-  Args g{};
-  g.A = (const bf16_t*)dH; g.B = (const bf16_t*)W1; g.C = dx; g.resid = dres;
-  g.lda = lda; g.ldb = ldb; g.ldc = N; g.ldr = N; g.M = M; g.N = N; g.K = K; g.alpha = 1.0f; g.direct = 1;
-  g.C16 = (bf16_t*)dx16; g.ldc16 = N; g.c1 = c1; g.c2 = c2;
-  g.gamma = gamma; g.xf = x; g.mean = mean; g.rstd = rstd; g.colpart = colpart;
-  return g3_launch(g, 5, 0, st);          // (c_fp32 = 0 here only keeps the 256-column tile for every K)
 }
 
 #ifdef CTCLIP_G3_STAMPS

@@ -32,16 +32,6 @@ struct Args {
   const bf16_t* xhat; long ldx;
   const float* c1; const float* c2;
   bf16_t* C16; long ldc16;
-  // EPI 6 = EPI 3 that also leaves, per row and 64-column slab of dg, the two sums the LayerNorm backward of the FF block is
-  // made of (the slab's 128 h columns j): rowpart[(slab * 3 + {0, 1, 2}) * ldrp + row] = sum_j d(pre)_j {wbar_j, bfold_j, pre_j},
-  // with wbar = W1 gamma and bfold = W1 beta in h's column order (ctclip_ff_fold_vectors); bfold may be NULL (beta = 0);
-  // ldrp = rows rounded up to a multiple of 16
-  const float* wbar; const float* bfold; float* rowpart; long ldrp; uint32_t vb_lds;
-  // EPI 5: the FF block's data gradient with its LayerNorm backward: acc = d(n2) = d(pre) W1;
-  //   C = rstd gamma acc - c1[row] - xhat c2[row] + resid,  xhat = (xf - mean) rstd   (f32, bf16 copy in C16),
-  //   colpart[(slot * 2) * N + col] = sum over the slot's 128 rows of acc (d(beta)), [(slot * 2 + 1) * N + col] = of acc xhat
-  //   (d(gamma)); slot = row / 128.  x, resid, C and C16 are dense [M, N] with M N < 2^31
-  const float* gamma; const float* xf; const float* mean; const float* rstd; float* colpart;
 };
 
 // [256 rows][32 k] bf16 tile, 64-byte rows, 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128 phase hit 16
@@ -112,14 +102,6 @@ __device__ __forceinline__ void unpack8(uint4 w, float* v) {
 // instruction cover rows 0-7 x 128 bytes and the second rows 8-15: measured +5..11 % on the K = 512 products.
 // After the call: s0 belongs to row (ml & 7), s1 to row 8 + (ml & 7), both at the half-line selected by ml >> 3.
 __device__ __forceinline__ uint32_t ror8(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false); }
-// sum over the 16 lanes of a DPP row (the ml lanes of one q4 group), in a fixed order: every lane ends with the total
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
-  return v;
-}
 __device__ __forceinline__ void line_pair(uint4 p0, uint4 p1, bool upper, uint4& s0, uint4& s1) {
   const uint4 send = upper ? p0 : p1;
   uint4 got;
@@ -141,104 +123,18 @@ __device__ __forceinline__ uint4 f4_bits(float a, float b, float c, float d) {
 // GENERIC = false leaves out the element-wise path for unaligned outputs (the caller then only takes g.direct problems).
 // EPI: 0 plain -> bf16   1 plain -> f32   (both: alpha, bias, residual, erf-GELU when g.act == 1)   2 FF1 + GEGLU
 //      3 FF2 data gradient + GEGLU backward   4 the f32 form with the LayerNorm backward applied (Args::xhat, c1, c2)
-//      5 FF1 data gradient + the FF block's LayerNorm backward and its d(gamma) / d(beta) column sums   6 = 3 + row sums for 5
 template <int EPI, int IM, int NJ, int J0, bool AHEAD, bool GENERIC = true>
 __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ], int rbase, int colw, int lane) {
   constexpr bool F32OUT = EPI == 1 || EPI == 4, LNB = EPI == 4;
   const int ml = lane & 15, q4 = lane >> 4;
-  const int act = EPI >= 2 ? EPI : g.act;   // (only the EPI < 2 forms look at it)
+  const int act = EPI >= 2 ? EPI : g.act;
   if (g.direct) {
     // ---- register epilogue: lane (q4, ml) owns, for each i, row 16 i + ml and (bf16) the slab columns 8 q4 .. +7 and
     //      32 + 8 q4 .. +7, (f32) 16 j + 4 q4 .. + 3.  Stores go out as whole lines (line_pair above); what the epilogue
     //      READS (residual, h) for row group i + 1 is requested before row group i is worked on.
     const bool upper = ml >= 8;
     const int rsub = ml & 7, hsel = ml >> 3;
-    if constexpr (EPI == 5) {
-      // lane (q4, ml): row 16 i + ml, f32 columns colw + 16 j + 4 q4 .. + 3.  The slab is worked in two 32-column halves (m;
-      // j = 2 m, 2 m + 1: the pair line_pair() turns into whole-line stores), each over all row groups, so that only one half's
-      // gamma values and column sums are live; a step = one row group of a half, and the residual, x and row constants of
-      // step + 1 are requested before step is worked on
-      const long slot = rbase >> 7;
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        float4 gm[2], sb[2], sg[2];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          const int col = colw + 16 * (2 * m + jj) + 4 * q4;
-          gm[jj] = col < g.N ? *(const float4*)(g.gamma + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-          sb[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
-          sg[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float4 rs[2][2], xs[2][2], rc[2];              // rc: this lane's row constants (c1, c2, mean, rstd)
-        // (x, the residual and both outputs are dense [M, N]: one 32-bit element index serves all four)
-        auto ld = [&](int i, float4 (&r)[2], float4 (&x)[2], float4& k) {
-          const int row = rbase + i * 16 + ml;
-          k = row < g.M ? make_float4(g.c1[row], g.c2[row], g.mean[row], g.rstd[row]) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int col = colw + 16 * (2 * m + jj) + 4 * q4;
-            const bool ok = row < g.M && col < g.N;
-            const int eo = row * g.N + col;
-            r[jj] = (ok && g.resid) ? *(const float4*)(g.resid + eo) : make_float4(0.f, 0.f, 0.f, 0.f);
-            x[jj] = ok ? *(const float4*)(g.xf + eo) : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-        };
-        if (AHEAD) ld(0, rs[0], xs[0], rc[0]);
-#pragma unroll
-        for (int i = 0; i < IM; ++i) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (AHEAD) { if (i + 1 < IM) ld(i + 1, rs[(i + 1) & 1], xs[(i + 1) & 1], rc[(i + 1) & 1]); }
-          else ld(i, rs[i & 1], xs[i & 1], rc[i & 1]);
-          const int rowl = rbase + i * 16 + ml;
-          const float live = rowl < g.M ? 1.f : 0.f;   // rows past M hold a copy of the last row's product
-          const float k1 = rc[i & 1].x, k2 = rc[i & 1].y, mu = rc[i & 1].z, rsd = rc[i & 1].w;
-          uint4 pk[2];
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int j = 2 * m + jj;
-            const int col = colw + 16 * j + 4 * q4;
-            const float4 xv = xs[i & 1][jj], rv = rs[i & 1][jj];
-            const float xin[4] = {xv.x, xv.y, xv.z, xv.w}, rin[4] = {rv.x, rv.y, rv.z, rv.w};
-            const float gmj[4] = {gm[jj].x, gm[jj].y, gm[jj].z, gm[jj].w};
-            float o[4], dl[4], xh[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float d = acc[i][J0 + j][e] * g.alpha;
-              xh[e] = (xin[e] - mu) * rsd;
-              dl[e] = d * live;
-              o[e] = rsd * gmj[e] * d - fmaf(xh[e], k2, k1) + rin[e];
-            }
-            sb[jj].x += dl[0]; sb[jj].y += dl[1]; sb[jj].z += dl[2]; sb[jj].w += dl[3];
-            sg[jj].x = fmaf(dl[0], xh[0], sg[jj].x); sg[jj].y = fmaf(dl[1], xh[1], sg[jj].y);
-            sg[jj].z = fmaf(dl[2], xh[2], sg[jj].z); sg[jj].w = fmaf(dl[3], xh[3], sg[jj].w);
-            pk[jj] = f4_bits(o[0], o[1], o[2], o[3]);
-            if (g.C16 && rowl < g.M && col < g.N)
-              *(uint2*)(g.C16 + (rowl * g.N + col)) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-          }
-          uint4 s0, s1;
-          line_pair(pk[0], pk[1], upper, s0, s1);
-          const int col = colw + 32 * m + 16 * hsel + 4 * q4;
-          const int row = rbase + i * 16 + rsub;
-          if (col < g.N) {
-            const int eo = row * g.N + col;
-            if (row < g.M) st16((float*)g.C + eo, s0);
-            if (row + 8 < g.M) st16((float*)g.C + (eo + 8 * g.N), s1);
-          }
-        }
-        // column sums of the wave's 128 rows: the 16 ml lanes of a q4 group hold the same columns
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          float4 b = sb[jj], c = sg[jj];
-          b.x = row16_sum(b.x); b.y = row16_sum(b.y); b.z = row16_sum(b.z); b.w = row16_sum(b.w);
-          c.x = row16_sum(c.x); c.y = row16_sum(c.y); c.z = row16_sum(c.z); c.w = row16_sum(c.w);
-          const int col = colw + 16 * (2 * m + jj) + 4 * q4;
-          if (ml == 0 && col < g.N) {
-            *(float4*)(g.colpart + (slot * 2) * g.N + col) = b;
-            *(float4*)(g.colpart + (slot * 2 + 1) * g.N + col) = c;
-          }
-        }
-      }
-    } else if constexpr (F32OUT) {
+        if constexpr (F32OUT) {
       float4 rs[2][4];
       auto ld_resid = [&](int i, float4 (&dst)[4]) {
         const int row = rbase + i * 16 + ml;
@@ -362,90 +258,6 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
             bf16_t* hp = g.G + (long)row * g.ldg + (long)(c >> 5) * 64 + 32 * hsel + (c & 31);
             if (row < g.M) st16(hp, s0);
             if (row + 8 < g.M) st16(hp + 8 * g.ldg, s1);
-          }
-        }
-      }
-    } else if constexpr (EPI == 6) {
-      // EPI 3 plus the row sums.  d(pre) of a row group, as stored (lane (ml, q4): row ml, 8 bf16 at block columns 8 q4 .. + 7),
-      // IS an operand of a 16x16x32 MFMA over the block's 32 columns; the other operand holds wbar in its row 0 and bfold in
-      // row 1 (bf16: their rounding is 1 / sqrt(dim) of the rounding the weights already carry), so D[m][n = row ml] leaves
-      // sum_j d(pre)_j wbar_j and sum_j d(pre)_j bfold_j of row ml in registers 0 and 1 of the lanes q4 = 0 -- no VALU work and
-      // no vector registers per column.  sum_j d(pre)_j pre_j is plain VALU on what the lane holds (before the
-      // rounding to bf16).
-      // The vector operands live in a 512-byte piece of LDS per wave (Args::vb_lds: behind the ring), [h][{value, gate}][q4][ml & 1]:
-      // held in registers they cost 16 of a budget the accumulators leave no room in.
-      extern __shared__ __attribute__((aligned(16))) char smem_e6[];
-      char* vbase = smem_e6 + g.vb_lds + (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) << 9);
-      if (ml < 2) {
-        const float* vp = ml == 0 ? g.wbar : g.bfold;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int c = colw + 32 * h + 8 * q4;
-          const long hc = (long)(c >> 5) * 64 + (c & 31);
-          const bool ok = c < g.N && vp;
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            float v[8];
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 a0 = ok ? *(const float4*)(vp + hc + 32 * t) : z, a1 = ok ? *(const float4*)(vp + hc + 32 * t + 4) : z;
-            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-            *(uint4*)(vbase + (((h * 2 + t) * 4 + q4) * 2 + ml) * 16) = pack8(v);
-          }
-        }
-      }
-      const char* vrd = vbase + (q4 * 2 + (ml & 1)) * 16;          // rows m >= 2 of the operand repeat rows 0 / 1: never looked at
-      uint4 hv[2][2];                                // [buffer][{value, gate}]: a step = one row group x one 32-column half
-      auto ld_h = [&](int step, uint4 (&dst)[2]) {
-        const int i = step >> 1, h = step & 1;
-        const int row = rbase + i * 16 + ml;
-        const int c = colw + 32 * h + 8 * q4;
-        const bf16_t* hp = g.G + (long)row * g.ldg + (long)(c >> 5) * 64 + (c & 31);
-        const bool ok = row < g.M && c < g.N;
-        dst[0] = ok ? *(const uint4*)hp : make_uint4(0u, 0u, 0u, 0u);
-        dst[1] = ok ? *(const uint4*)(hp + 32) : make_uint4(0u, 0u, 0u, 0u);
-      };
-      if (AHEAD) ld_h(0, hv[0]);
-      float* rp = g.rowpart + (long)(colw >> 6) * 3 * g.ldrp;     // [slab][{wbar sum, bfold sum, pre sum}][rows rounded up to 16]
-      f32x4 d2 = {0.f, 0.f, 0.f, 0.f};
-      float s3 = 0.f;                                  // (rows past M, columns past N: h was read as zeros, so d(pre) = 0)
-#pragma unroll
-      for (int step = 0; step < 2 * IM; ++step) {
-        const int i = step >> 1, h = step & 1;
-        __builtin_amdgcn_sched_barrier(0);
-        if (AHEAD) { if (step + 1 < 2 * IM) ld_h(step + 1, hv[(step + 1) & 1]); }
-        else ld_h(step, hv[step & 1]);
-        if (h == 0) { d2 = f32x4{0.f, 0.f, 0.f, 0.f}; s3 = 0.f; }
-        float val[8], gate[8], dv[8], dt[8];
-        unpack8(hv[step & 1][0], val);
-        unpack8(hv[step & 1][1], gate);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float dgv = acc[i][J0 + 2 * h + (e >> 2)][e & 3] * g.alpha;
-          dv[e] = dgv * gelu_erf(gate[e]);
-          dt[e] = dgv * val[e] * gelu_erf_grad_fast(gate[e]);
-          s3 = fmaf(dv[e], val[e], s3);
-          s3 = fmaf(dt[e], gate[e], s3);
-        }
-        const uint4 pv = pack8(dv), pt = pack8(dt);
-        d2 = mfma16(*(const bf16x8*)(vrd + (h * 2) * 128), __builtin_bit_cast(bf16x8, pv), d2);
-        d2 = mfma16(*(const bf16x8*)(vrd + (h * 2 + 1) * 128), __builtin_bit_cast(bf16x8, pt), d2);
-        uint4 s0, s1;
-        line_pair(pv, pt, upper, s0, s1);
-        const int c = colw + 32 * h + 8 * q4;
-        const int row = rbase + i * 16 + rsub;
-        if (c < g.N) {
-          bf16_t* hp = g.G + (long)row * g.ldg + (long)(c >> 5) * 64 + 32 * hsel + (c & 31);
-          if (row < g.M) st16(hp, s0);
-          if (row + 8 < g.M) st16(hp + 8 * g.ldg, s1);
-        }
-        if (h == 1) {
-          s3 += __shfl_xor(s3, 16, 64);
-          s3 += __shfl_xor(s3, 32, 64);
-          const int r16 = rbase + i * 16;
-          if (colw < g.N && r16 < g.ldrp && q4 == 0) {     // D[m = vector][n = row ml]: the lanes q4 = 0 hold m = 0, 1 of row ml
-            rp[r16 + ml] = d2[0];
-            rp[g.ldrp + r16 + ml] = d2[1];
-            rp[2 * g.ldrp + r16 + ml] = s3;
           }
         }
       }

@@ -367,52 +367,6 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restr
   }
 }
 
-
-// ---- the FF block's LayerNorm backward inside its two data-gradient products (gemm_tile.h, EPI 6 and EPI 5) ----
-// wbar[j] = sum_k W[j][k] gamma[k], bfold[j] = sum_k W[j][k] beta[k] over the rows of the bf16 FF1 weight as the GEMMs read it
-// (nn.Sequential(LayerNorm, Linear): attention.py:43-47).  One wave per row.
-__global__ __launch_bounds__(256) void ff_fold_vectors_kernel(const bf16_t* __restrict__ W, long ldw, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ wbar,
-                                                              float* __restrict__ bfold, int rows, int dim) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  float a = 0.f, b = 0.f;
-  for (int k = lane * 8; k < dim; k += 512) {
-    float w[8];
-    const uint4 raw = *(const uint4*)(W + (long)row * ldw + k);
-    const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { w[2 * e] = __uint_as_float(u[e] << 16); w[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u); }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      a = fmaf(w[e], gamma[k + e], a);
-      if (beta) b = fmaf(w[e], beta[k + e], b);
-    }
-  }
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-  if (lane == 0) { wbar[row] = a; bfold[row] = b; }
-}
-
-// the row constants of EPI 5 from the per-slab sums EPI 6 left: c1 = rstd / dim * sum_s P[s][0], c2 = rstd / dim * sum_s (P[s][2] -
-// P[s][1]) -- slabs added in index order
-__global__ __launch_bounds__(256) void ff_rowconst_kernel(const float* __restrict__ rowpart, long ldrp, int nslab,
-                                                          const float* __restrict__ rstd, float inv_dim, float* __restrict__ c1,
-                                                          float* __restrict__ c2, int rows) {
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  if (row >= rows) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int s = 0; s < nslab; ++s) {
-    const float* p = rowpart + (long)s * 3 * ldrp + row;
-    s1 += p[0];
-    s2 += p[2 * ldrp] - p[ldrp];
-  }
-  const float k = rstd[row] * inv_dim;
-  c1[row] = k * s1;
-  c2[row] = k * s2;
-}
-
 }  // namespace
 
 // workgroups of the LayerNorm backward: every wave at least 8 rows (the partial rows are summed by a second kernel whose
@@ -581,25 +535,6 @@ int ctclip_headnorm_bwd_ln(const void* dy, const void* x, const float* inv_norm,
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return ctclip_reduce_partials(partials, (int)blocks, dhead, dhead, dscale, (hipStream_t)stream);
-}
-
-int ctclip_ff_fold_vectors(const void* w1_bf16, long ldw, const float* gamma, const float* beta, float* wbar, float* bfold, int rows,
-                           int dim, void* stream) {
-  if (rows <= 0) return 0;
-  if (!w1_bf16 || !gamma || !wbar || !bfold || dim <= 0 || (dim & 7) || (ldw & 7) || (((uintptr_t)w1_bf16) & 15))
-    return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(ff_fold_vectors_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)w1_bf16, ldw, gamma, beta, wbar, bfold, rows, dim);
-  CTCLIP_CHECK_LAUNCH();
-}
-
-int ctclip_ff_rowconst(const float* rowpart, long ldrp, int nslab, const float* rstd, int dim, float* c1, float* c2, int rows,
-                       void* stream) {
-  if (rows <= 0) return 0;
-  if (!rowpart || !rstd || !c1 || !c2 || nslab <= 0 || dim <= 0 || ldrp < rows) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(ff_rowconst_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rowpart, ldrp,
-                     nslab, rstd, 1.0f / (float)dim, c1, c2, rows);
-  CTCLIP_CHECK_LAUNCH();
 }
 
 }  // extern "C"

@@ -10,7 +10,6 @@ softmax statistics / losses / optimiser are f32.
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 from torch.autograd import Function
@@ -27,20 +26,6 @@ def bump_weight_epoch() -> None:
     """Call after parameters were updated through raw pointers (the fused optimiser does)."""
     global _weight_epoch
     _weight_epoch += 1
-
-
-_V2_ALL = os.environ.get("CTCLIP_GEMM_V2_ALL") is not None     # the tests' size-gate hook (csrc/common.h): small shapes take the fused paths
-_scratch_bufs = {}
-
-
-def _scratch(name, numel, device):
-    """A float32 work buffer that lives across calls (per device and current stream, like lib.partials_scratch): kernels of one
-    stream run in order, so consecutive layers share it."""
-    key = (name, device, torch.cuda.current_stream().cuda_stream)
-    t = _scratch_bufs.get(key)
-    if t is None or t.numel() < numel:
-        t = _scratch_bufs[key] = torch.empty(numel, dtype=F32, device=device)
-    return t
 
 
 class ShadowCache:
@@ -813,21 +798,9 @@ class FeedForwardFn(Function):
         w2T = sh["w2T"]
         small = ((M + 255) // 256) * ((Ip + 255) // 256) < 192
         scratch = torch.empty(M, Ip, dtype=BF16, device=dy.device) if small else None
-        # With enough tiles for the LDS-DMA kernels the block's LayerNorm backward is taken INSIDE the two data-gradient products
-        # (include/ctclip_hip.h, ctclip_gemm_bf16_ffln): the product above also leaves the row sums of d(pre) the LayerNorm
-        # backward is made of, the FF1 data gradient finishes dx, d(gamma), d(beta) in its epilogue -- d(n2) never exists
-        tiles = ((M + 255) // 256) * ((Ip + 255) // 256)
-        fused_ln = "wbar" in sh and "w1T" in sh and dim % 64 == 0 and M * dim < 2 ** 31 and (tiles >= 192 or (_V2_ALL and tiles >= 4))
-        if fused_ln:
-            nslab, ldrp = Ip // 64, (M + 15) // 16 * 16
-            rowpart = _scratch("ff_rowpart", nslab * 3 * ldrp, dy.device)
-            hip.gemm_bf16_geglu_bwd_rows(dyb, w2T, h, M, Ip, dim, dyb.stride(0), w2T.stride(0), 2 * Ip, sh["wbar"], sh["bfold"],
-                                         rowpart)
-        else:
-            hip.gemm_bf16_geglu_bwd(dyb, w2T, h, scratch, M, Ip, dim, dyb.stride(0), w2T.stride(0), 2 * Ip, Ip)
+        hip.gemm_bf16_geglu_bwd(dyb, w2T, h, scratch, M, Ip, dim, dyb.stride(0), w2T.stride(0), 2 * Ip, Ip)
         dh = h
-        if not fused_ln:
-            dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim, out_dtype=BF16, wT16=sh.get("w1T"))
+        dn2 = dgrad(dh, sh["w1"], M, 2 * Ip, dim, out_dtype=BF16, wT16=sh.get("w1T"))
         # one product over all 2*Ip columns of dh (the pad columns are zero): n2 is streamed once and 2*Ip = 2816 is a
         # whole number of 256-row tiles, where two I = 1365-row products each round up to six
         def ff1_wgrad():
@@ -837,14 +810,7 @@ class FeedForwardFn(Function):
         on_side_stream(ff1_wgrad, dh, n2, gw1)
         dx = torch.empty(M, dim, dtype=F32, device=dy.device)
         dx16 = torch.empty(M, dim, dtype=BF16, device=dy.device)
-        if fused_ln:
-            c12 = _scratch("ff_c12", 2 * M, dy.device)
-            colpart = _scratch("ff_colpart", (M + 255) // 256 * 2 * 2 * dim, dy.device)
-            w1T = sh["w1T"]                              # [dim, 2 Ip]: the k-major operand of d(n2) = d(h) W1
-            hip.gemm_bf16_ffln(dh, w1T, dx, dx16, M, dim, 2 * Ip, dh.stride(0), w1T.stride(0), ln_w.detach(), x2, mean, rstd, rowpart,
-                               nslab, dy2 if ctx.residual else None, c12, colpart, glw, glb)
-        else:
-            hip.layernorm_bwd_bf16(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, None, dx, dx16, glw, glb, M, dim)
+        hip.layernorm_bwd_bf16(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, None, dx, dx16, glw, glb, M, dim)
         return _tag16(dx.reshape(dy.shape), dx16), _ret(glw, d3), _ret(glb, d4), _ret(gw1, d1), _ret(gw2, d2), None, None
 
 

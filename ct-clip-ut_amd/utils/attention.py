@@ -77,7 +77,7 @@ class FeedForward(nn.Sequential):
         self._shadow = ops.ShadowCache()
 
     def _shadows(self):
-        ln, w1, w2 = self[0], self[1].weight, self[4].weight
+        w1, w2 = self[1].weight, self[4].weight
         I, Ip = self.inner, ops.pad64(self.inner)      # 1365 -> 1408: every K of the MLP is a whole number of 64-wide k-tiles
 
         def make():
@@ -95,16 +95,10 @@ class FeedForward(nn.Sequential):
             S.add(w1[I:], w1T[:, blk:], transpose=True, blk=blk)
             S.add(w2, w2p)
             S.add(w2, w2T, transpose=True)
-            # wbar = W1 gamma and bfold = W1 beta in h's column order: the LayerNorm backward of the block is taken inside its two
-            # data-gradient products (include/ctclip_hip.h, ctclip_gemm_bf16_ffln) and these are the vectors its row sums need
-            wbar, bfold = S.zeros(2 * Ip, dtype=F32), S.zeros(2 * Ip, dtype=F32)
-            for vec, sc in ((wbar, ln.weight), (bfold, ln.bias)):
-                S.add(w1[:I], vec, blk=blk, scale=sc, rowsum=True)
-                S.add(w1[I:], vec[blk:], blk=blk, scale=sc, rowsum=True)
-            S.out = {"w1": w1p, "w2": w2p, "w1T": w1T, "w2T": w2T, "inner": I, "inner_p": Ip, "wbar": wbar, "bfold": bfold}
+            S.out = {"w1": w1p, "w2": w2p, "w1T": w1T, "w2T": w2T, "inner": I, "inner_p": Ip}
             return S
 
-        return self._shadow.get_set("ff", (w1, w2, ln.weight, ln.bias), make)
+        return self._shadow.get_set("ff", (w1, w2), make)
 
     def forward(self, x, residual: bool = False):
         _need_cuda(x, "FeedForward")

@@ -121,36 +121,6 @@ int ctclip_layernorm_bwd_xhat(const void* dy_bf16, const void* xhat_bf16, const 
 int ctclip_gemm_bf16_lnbwd(const void* A, const void* B, float* dx, void* dx_bf16, int M, int N, int K, long lda, long ldb,
                            const void* xhat, const float* c1, const float* c2, const float* dres, void* stream);
 
-/* The LayerNorm backward of a FEED-FORWARD block inside its two data-gradient products (attention.py:43-51 backward;
- * nn.Sequential(LayerNorm(dim), Linear(dim, 2 inner, bias=False), GEGLU, Dropout, Linear(inner, dim, bias=False))).  With
- * n2 = gamma xhat + beta, pre = n2 W1^T and d(n2) = d(pre) W1:
- *   dx = rstd (gamma d(n2) - mean_k(gamma d(n2)) - xhat mean_k(gamma d(n2) xhat)) + dres
- *   sum_k gamma_k d(n2)_k       = sum_j d(pre)_j wbar_j,             wbar  = W1 gamma
- *   sum_k gamma_k d(n2)_k xhat_k = sum_j d(pre)_j (pre_j - bfold_j),  bfold = W1 beta
- * so both row sums can be taken where d(pre) is PRODUCED -- the epilogue of the FF2 data-gradient product that applies the
- * GEGLU backward and has pre in its registers -- and the FF1 data-gradient product can finish dx in its own epilogue: the
- * [tokens, dim] gradient d(n2) never goes to memory and there is no separate LayerNorm-backward pass.
- *   ctclip_ff_fold_vectors: wbar / bfold [rows] from the bf16 weight the GEMMs read (rows = 2 inner_padded in h's column order,
- *     row stride ldw) -- once per weight update; beta may be NULL (bfold = 0).
- *   ctclip_gemm_bf16_geglu_bwd_rows: ctclip_gemm_bf16_geglu_bwd (h <- d(h) in place) that also writes
- *     rowpart[(slab * 3 + {0, 1, 2}) * ldrp + row] = sum over the slab's 128 h columns of d(pre)_j {wbar_j, bfold_j, pre_j},
- *     slab = 0 .. inner / 64 - 1, ldrp = M rounded up to 16.  K % 32 == 0, inner % 64 == 0; no small-problem form.
- *   ctclip_gemm_bf16_ffln: dx = [the formula above] from A = d(h) [M, K = 2 inner_padded] bf16 and B = W1 [N = dim, K] bf16;
- *     x [M, N] f32 (the LayerNorm's input), mean / rstd [M] as saved by the forward, dres [M, N] f32 or NULL, dx [M, N] f32,
- *     dx_bf16 optional; dgamma / dbeta [N] are ACCUMULATED into (either may be NULL).  Scratch: c12 [2 M] floats, colpart
- *     [2 ceil(M / 256)][2][N] floats (per-128-row column sums, added up in order by the two-stage reduction).  M N < 2^31.
- * ctclip_ff_rowconst (called by ctclip_gemm_bf16_ffln; exported for the tests): c1 / c2 [rows] from rowpart. */
-int ctclip_ff_fold_vectors(const void* w1_bf16, long ldw, const float* gamma, const float* beta, float* wbar, float* bfold, int rows,
-                           int dim, void* stream);
-int ctclip_ff_rowconst(const float* rowpart, long ldrp, int nslab, const float* rstd, int dim, float* c1, float* c2, int rows,
-                       void* stream);
-int ctclip_gemm_bf16_geglu_bwd_rows(const void* dY, const void* W2T, void* H_dH, int M, int inner, int K, long lddy, long ldw,
-                                    long ldh, const float* wbar, const float* bfold, float* rowpart, void* stream);
-int ctclip_gemm_bf16_ffln(const void* dH, const void* W1, float* dx, void* dx_bf16, int M, int N, int K, long lda, long ldb,
-                          const float* gamma, const float* x, const float* mean, const float* rstd, const float* rowpart, int nslab,
-                          const float* dres, float* c12, float* colpart, float* dgamma, float* dbeta, float* partials,
-                          void* stream);
-
 /* ---- per-head cosine normalisation: y = x/|x| * scale[d] * mult   (attention.py:151-153,155) ----
  * x_hm_n / y_hm_n > 0: that operand is in the HEAD-MAJOR layout [sequence][head][token][dhead] with x_hm_n tokens per
  * sequence (rows % x_hm_n == 0; its ld is ignored) -- the operand layout of ctclip_attn_hm_*; 0: row-major [rows, ld]. */

@@ -1157,86 +1157,6 @@ def test_attention_input_gradient_with_layernorm_backward_in_the_gemm(hip):
     check("dx without the residual gradient", dx, want - dres, 6e-3)
 
 
-@pytest.mark.parametrize("M,Ip,with_beta", [(1000, 192, True), (1536, 320, False), (130, 64, True)])
-def test_feed_forward_input_gradient_with_layernorm_backward_in_the_gemms(hip, M, Ip, with_beta):
-    """ctclip_ff_fold_vectors + ctclip_gemm_bf16_geglu_bwd_rows + ctclip_gemm_bf16_ffln: the input gradient of a feed-forward
-    block (attention.py:43-51 backward) with the LayerNorm backward split over the epilogues of its two data-gradient products,
-    against f32 torch math of the chain it replaces (FF2 data gradient -> GEGLU backward -> FF1 data gradient -> LayerNorm
-    backward + residual gradient, d(gamma), d(beta)).  h is in the interleaved [value 32 | gate 32] block order the kernels
-    use.  Ragged row counts, a width that is not a whole column tile, beta = None, gradients accumulated on top of what the
-    buffers hold."""
-    dim = 512
-    x = rnd(M, dim, seed=160) * 1.5 + 0.2
-    gamma = 1 + 0.2 * rnd(dim, seed=161)
-    beta = 0.3 * rnd(dim, seed=162) if with_beta else None
-    w1 = bf(rnd(2 * Ip, dim, seed=163) * 0.05)                                # rows in h's column order
-    w2T = bf(rnd(Ip, dim, seed=164) * 0.05)                                   # [inner, dim]: dg = dy w2T^T
-    dy, dres = bf(rnd(M, dim, seed=165)), rnd(M, dim, seed=166)
-    # forward quantities the way the block saves them
-    n2 = torch.empty(M, dim, device=DEV, dtype=torch.bfloat16)
-    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
-    hip.layernorm_fwd(x, gamma, beta, n2, None, mean, rstd, M, dim, 1e-5)
-    h = bf(n2.float() @ w1.float().t())                                       # pre-activations as FF1 rounds them
-    xh = (x - mean[:, None]) * rstd[:, None]
-    # the chain it replaces: EPI 3 product (bit-identical d(h) expected), then f32 math
-    dh_ref = h.clone()
-    hip.gemm_bf16_geglu_bwd(dy, w2T, dh_ref, torch.empty(M, Ip, device=DEV, dtype=torch.bfloat16), M, Ip, dim, dim, dim, 2 * Ip, Ip)
-    exact = ((M + 255) // 256) * ((Ip + 255) // 256) >= 4        # (smaller: the reference call takes its two-kernel form)
-    w1T = w1.t().contiguous()                                                 # [dim, 2 Ip]: d(n2) = d(h) W1 as A B^T
-    dn2 = dh_ref.float() @ w1.float()
-    dnh = dn2 * gamma
-    want = rstd[:, None] * (dnh - dnh.mean(1, keepdim=True) - xh * (dnh * xh).mean(1, keepdim=True)) + dres
-    # fused pair
-    wbar, bfold = torch.empty(2 * Ip, device=DEV), torch.empty(2 * Ip, device=DEV)
-    hip.ff_fold_vectors(w1, dim, gamma, beta, wbar, bfold, 2 * Ip, dim)
-    check("wbar = W1 gamma", wbar, w1.float() @ gamma, 1e-5)
-    check("bfold = W1 beta", bfold + 1.0, (w1.float() @ beta if with_beta else torch.zeros_like(bfold)) + 1.0, 1e-5)
-    nslab, ldrp = Ip // 64, (M + 15) // 16 * 16
-    rowpart = torch.full((nslab, 3, ldrp), float("nan"), device=DEV)
-    dh = h.clone()
-    hip.gemm_bf16_geglu_bwd_rows(dy, w2T, dh, M, Ip, dim, dim, dim, 2 * Ip, wbar, bfold if with_beta else None, rowpart)
-    if exact:
-        assert torch.equal(dh, dh_ref), "d(h) differs from the plain GEGLU-backward product"
-    else:
-        check("d(h)", dh, dh_ref, 1.5e-2)
-        dh_ref = dh.clone()
-        dn2 = dh_ref.float() @ w1.float()
-        dnh = dn2 * gamma
-        want = rstd[:, None] * (dnh - dnh.mean(1, keepdim=True) - xh * (dnh * xh).mean(1, keepdim=True)) + dres
-    dpre, pre = dh.float(), h.float()
-    part = lambda v: (dpre * v).view(M, nslab, 128).sum(-1).t()                # [nslab, M]
-    check("row sums with wbar", rowpart[:, 0, :M], part(wbar[None, :]), 1.5e-2)
-    check("row sums with pre", rowpart[:, 2, :M], part(pre), 6e-3)     # (the kernel sums before d(pre) is rounded)
-    if with_beta:
-        check("row sums with bfold", rowpart[:, 1, :M], part(bfold[None, :]), 1.5e-2)
-    else:
-        assert float(rowpart[:, 1, :M].abs().max()) == 0.0
-    c12 = torch.empty(2, M, device=DEV)
-    hip.ff_rowconst(rowpart, ldrp, nslab, rstd, dim, c12[0], c12[1], M)
-    check("c1", c12[0], rstd * dnh.mean(1), 6e-3)            # wbar enters its MFMA as bf16
-    check("c2", c12[1], rstd * (dnh * xh).mean(1), 6e-3)
-    colpart = torch.full(((M + 255) // 256 * 2, 2, dim), float("nan"), device=DEV)
-    dx, dx16 = torch.empty(M, dim, device=DEV), torch.empty(M, dim, device=DEV, dtype=torch.bfloat16)
-    g0, b0 = rnd(dim, seed=167), rnd(dim, seed=168)
-    dgam, dbet = g0.clone(), b0.clone()
-    c12.fill_(float("nan"))
-    hip.gemm_bf16_ffln(dh, w1T, dx, dx16, M, dim, 2 * Ip, 2 * Ip, 2 * Ip, gamma, x, mean, rstd, rowpart, nslab, dres, c12, colpart,
-                       dgam, dbet)
-    check("dx = LN'(d(h) W1) + dres", dx, want, 3e-3)
-    check("bf16 copy of dx", dx16, want, 1e-2)
-    check("d(gamma)", dgam - g0, (dn2 * xh).sum(0), 2e-3)
-    check("d(beta)", dbet - b0, dn2.sum(0), 2e-3)
-    dx2 = torch.empty_like(dx)
-    hip.gemm_bf16_ffln(dh, w1T, dx2, None, M, dim, 2 * Ip, 2 * Ip, 2 * Ip, gamma, x, mean, rstd, rowpart, nslab, None, c12, colpart,
-                       None, None)
-    check("dx without the residual gradient", dx2, want - dres, 3e-3)
-    # bit-identical from run to run (no atomics anywhere in the pair)
-    dx3, dgam3 = torch.empty_like(dx), g0.clone()
-    hip.gemm_bf16_ffln(dh, w1T, dx3, None, M, dim, 2 * Ip, 2 * Ip, 2 * Ip, gamma, x, mean, rstd, rowpart, nslab, dres, c12, colpart,
-                       dgam3, None)
-    assert torch.equal(dx3, dx) and torch.equal(dgam3, dgam)
-
-
 def test_bert_embedding_backward_without_atomics(hip):
     """ctclip_bert_embed_bwd (transformers BertEmbeddings backward): d(word) / d(position) / d(token type) against
     torch's index_add on the same inputs -- ids with many repeats (and one id used by every row of a sequence), on top of
