@@ -90,6 +90,35 @@ __device__ __forceinline__ float gelu_erf_grad_fast(float x) {
   return fmaf(x * 0.3989422804014327f, __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x), norm_cdf_fast(x));
 }
 
+// The same two functions on PAIRS of values: the polynomial, the products and the sums become packed-f32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work per issue slot on CDNA3+), which is what the GEGLU epilogues of the
+// GEMM tiles are bound by (64-128 evaluations per lane and tile next to a matrix loop of 16 K-steps).  Operation for operation
+// the arithmetic of norm_cdf_fast / gelu_erf_fast / gelu_erf_grad_fast: the results are bit-identical.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_splat(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 norm_cdf_fast2(f32x2 x) {
+  const f32x2 xc = {__builtin_amdgcn_fmed3f(x.x, -3.7f, 3.7f), __builtin_amdgcn_fmed3f(x.y, -3.7f, 3.7f)};
+  const f32x2 w = xc * xc;
+  f32x2 q = pk_fma(pk_splat(4.174217594e-08f), w, pk_splat(-2.483551043e-06f));
+  q = pk_fma(q, w, pk_splat(6.402253348e-05f));
+  q = pk_fma(q, w, pk_splat(-9.565735236e-04f));
+  q = pk_fma(q, w, pk_splat(9.406451136e-03f));
+  q = pk_fma(q, w, pk_splat(-6.585516781e-02f));
+  q = pk_fma(q, w, pk_splat(3.987334669e-01f));
+  const f32x2 r = pk_fma(x - xc, pk_splat(1e30f), pk_fma(xc, q, pk_splat(0.5f)));
+  return f32x2{__builtin_amdgcn_fmed3f(r.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(r.y, 0.f, 1.f)};
+}
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) { return x * norm_cdf_fast2(x); }
+// gelu(x) and d/dx gelu(x) of a pair from ONE evaluation of Phi
+__device__ __forceinline__ void gelu_erf_both2(f32x2 x, f32x2& gelu, f32x2& grad) {
+  const f32x2 cdf = norm_cdf_fast2(x);
+  const f32x2 t = (pk_splat(-0.72134752044448170f) * x) * x;
+  const f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+  gelu = x * cdf;
+  grad = pk_fma(x * pk_splat(0.3989422804014327f), e, cdf);
+}
+
 // ----- wave-level reductions (64 lanes) -------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

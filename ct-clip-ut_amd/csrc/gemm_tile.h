@@ -205,7 +205,10 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
           for (int e = 0; e < 8; ++e) v[h][e] = acc[i][J0 + 2 * h + (e >> 2)][e & 3] * g.alpha;
         float w[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) w[e] = gelu_erf(v[1][e]) * v[0][e];
+        for (int e = 0; e < 8; e += 2) {               // pairs: packed-f32 arithmetic (common.h)
+          const f32x2 ge = gelu_erf_fast2(f32x2{v[1][e], v[1][e + 1]}) * f32x2{v[0][e], v[0][e + 1]};
+          w[e] = ge.x; w[e + 1] = ge.y;
+        }
         uint4 s0, s1;
         line_pair(pack8(v[0]), pack8(v[1]), upper, s0, s1);
         const int row = rbase + i * 16 + rsub;
@@ -245,10 +248,12 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
           unpack8(hv[i & 1][2 * h], val);
           unpack8(hv[i & 1][2 * h + 1], gate);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float dgv = acc[i][J0 + 2 * h + (e >> 2)][e & 3] * g.alpha;
-            dv[e] = dgv * gelu_erf(gate[e]);
-            dt[e] = dgv * val[e] * gelu_erf_grad_fast(gate[e]);
+          for (int e = 0; e < 8; e += 2) {             // pairs: packed-f32 arithmetic, one Phi for gelu and its derivative
+            const f32x2 dgv = f32x2{acc[i][J0 + 2 * h + (e >> 2)][e & 3], acc[i][J0 + 2 * h + (e >> 2)][(e & 3) + 1]} * pk_splat(g.alpha);
+            f32x2 ge, gr;
+            gelu_erf_both2(f32x2{gate[e], gate[e + 1]}, ge, gr);
+            const f32x2 a = dgv * ge, b = (dgv * f32x2{val[e], val[e + 1]}) * gr;
+            dv[e] = a.x; dv[e + 1] = a.y; dt[e] = b.x; dt[e + 1] = b.y;
           }
           uint4 s0, s1;
           line_pair(pack8(dv), pack8(dt), upper, s0, s1);
