@@ -11,6 +11,8 @@ REPO=$OLDPWD
 STEPS=${STEPS:-10}; WARM=${WARM:-3}; BATCH=${BATCH:-96}
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/stats -o stats -- python3 $REPO/bench.py --lean --batch $BATCH --steps $STEPS --warmup $WARM > $OUT/${TAG}_bench_under_profiler.json 2> $OUT/${TAG}_stats.err
 python3 $REPO/tools/prof_summary.py $(find $OUT/prof_$TAG/stats -name '*kernel_stats.csv' | head -1) $((STEPS + WARM + 2)) $OUT/${TAG}_default_bench_b${BATCH}_kernel_stats.csv > /dev/null
+# the framework's own small kernels by call site (previous / next kernel), per step
+python3 $REPO/tools/trace_glue.py $(find $OUT/prof_$TAG/stats -name '*kernel_trace.csv' | head -1) $((STEPS + WARM + 2)) > $OUT/${TAG}_glue.txt 2>&1 || true
 if [ "${PMC:-1}" = "1" ]; then
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_$TAG/fetch -o fetch -- python3 $REPO/bench.py --lean --batch $BATCH --steps 3 --warmup 2 > /dev/null 2> $OUT/${TAG}_fetch.err
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_$TAG/write -o write -- python3 $REPO/bench.py --lean --batch $BATCH --steps 3 --warmup 2 > /dev/null 2> $OUT/${TAG}_write.err
