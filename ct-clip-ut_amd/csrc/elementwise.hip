@@ -490,6 +490,34 @@ int ctclip_dropout_bwd(const float* g, float* d, void* d_bf16, long n, float p, 
 }
 }
 
+// ---- FF1 weight gradient: rows of the product come in the [value blk | gate blk | ...] block order of the GEGLU weight
+// shadow; dw [2 inner, dim] += them in the reference's order (value rows 0 .. inner - 1, gate rows inner .. 2 inner - 1).
+namespace {
+__global__ __launch_bounds__(256) void geglu_wgrad_unblock_kernel(const float4* __restrict__ gp, float4* __restrict__ dw, int inner,
+                                                                  int blk, int d4) {
+  const long total = 2L * inner * d4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % d4);
+    const int r = (int)(e / d4);                       // reference row
+    const int gate = r >= inner, q = gate ? r - inner : r;
+    const long src = ((long)(q / blk) * 2 + gate) * blk + q % blk;
+    const float4 a = gp[src * d4 + c];
+    float4 b = dw[e];
+    b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+    dw[e] = b;
+  }
+}
+}  // namespace
+
+extern "C" int ctclip_geglu_wgrad_unblock(const float* g_blocked, float* dw, int inner, int block, int dim, void* stream) {
+  if (inner <= 0 || dim <= 0) return 0;
+  if (block <= 0 || (dim & 3) || ((((uintptr_t)g_blocked) | ((uintptr_t)dw)) & 15)) return (int)hipErrorInvalidValue;
+  const long total = 2L * inner * (dim / 4);
+  hipLaunchKernelGGL(geglu_wgrad_unblock_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)g_blocked,
+                     (float4*)dw, inner, block, dim / 4);
+  CTCLIP_CHECK_LAUNCH();
+}
+
 // ---- weight shadows: every kernel-layout copy of the model's parameters in ONE launch per optimiser step ------------------------
 // The GEMM kernels read bf16 (and transposed, zero-padded, block-interleaved, gamma-scaled) copies of the f32 master weights;
 // rebuilding them with framework ops took ~180 small launches per step.  Here a table of descriptors -- written once, when

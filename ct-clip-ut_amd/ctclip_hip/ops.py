@@ -804,9 +804,8 @@ class FeedForwardFn(Function):
         # one product over all 2*Ip columns of dh (the pad columns are zero): n2 is streamed once and 2*Ip = 2816 is a
         # whole number of 256-row tiles, where two I = 1365-row products each round up to six
         def ff1_wgrad():
-            gw1p = wgrad(dh, n2, 2 * Ip, dim, M).view(Ip // GEGLU_BLOCK, 2, GEGLU_BLOCK, dim)   # rows in the interleaved [val | gate] block order
-            gw1[:I] += gw1p[:, 0].reshape(Ip, dim)[:I]             # value half  (rows 0..I-1 of the reference weight)
-            gw1[I:] += gw1p[:, 1].reshape(Ip, dim)[:I]             # gate half   (rows I..2I-1)
+            gw1p = wgrad(dh, n2, 2 * Ip, dim, M)                   # rows in the interleaved [val | gate] block order
+            hip.geglu_wgrad_unblock(gw1p, gw1, I, GEGLU_BLOCK, dim)    # += value rows 0..I-1, gate rows I..2I-1 of the reference weight
         on_side_stream(ff1_wgrad, dh, n2, gw1)
         dx = torch.empty(M, dim, dtype=F32, device=dy.device)
         dx16 = torch.empty(M, dim, dtype=BF16, device=dy.device)

@@ -321,7 +321,11 @@ int ctclip_dropout_keep(uint8_t* keep, long n, float p, long seed, long offset, 
 int ctclip_dropout_add(const float* x, const float* branch, float* out, long n, float p, long seed, long offset,
                        void* stream);                                                             /* out = x + keep branch / (1-p) */
 int ctclip_dropout_bwd(const float* g, float* d, void* d_bf16, long n, float p, long seed, long offset,
-                       void* stream);                                                             /* d = keep g / (1-p), f32 and/or bf16 */
+                       void* stream);
+/* FF1 weight gradient out of the blocked order: g_blocked [2 inner_padded, dim] f32 is the product d(h)^T n2 with rows in the
+ * [value `block` | gate `block` | ...] order of the GEGLU weight shadow (ctclip_gemm_bf16_geglu); dw [2 inner, dim] (the
+ * nn.Linear(dim, 2 inner) weight of attention.py:47: value rows, then gate rows) += its rows.  dim % 4 == 0. */
+int ctclip_geglu_wgrad_unblock(const float* g_blocked, float* dw, int inner, int block, int dim, void* stream);                                                             /* d = keep g / (1-p), f32 and/or bf16 */
 
 /* ---- BERT embeddings (transformers BertEmbeddings): word[ids] + pos[0..L) + type[token_type] ---- */
 int ctclip_bert_embed_fwd(const long* ids, const long* token_type, const float* word, const float* pos, const float* type,

@@ -1157,6 +1157,21 @@ def test_attention_input_gradient_with_layernorm_backward_in_the_gemm(hip):
     check("dx without the residual gradient", dx, want - dres, 6e-3)
 
 
+def test_feed_forward_weight_gradient_out_of_the_blocked_order(hip):
+    """ctclip_geglu_wgrad_unblock: rows of the FF1 weight-gradient product come in [value 32 | gate 32 | ...] blocks of the padded
+    width; the nn.Linear(dim, 2 inner) gradient (value rows, then gate rows: attention.py:47) accumulates them -- exactly."""
+    I, Ip, dim, blk = 85, 128, 24, 32
+    gp = rnd(2 * Ip, dim, seed=170)
+    dw0 = rnd(2 * I, dim, seed=171)
+    want = dw0.clone()
+    v = gp.view(Ip // blk, 2, blk, dim)
+    want[:I] += v[:, 0].reshape(Ip, dim)[:I]
+    want[I:] += v[:, 1].reshape(Ip, dim)[:I]
+    dw = dw0.clone()
+    hip.geglu_wgrad_unblock(gp, dw, I, blk, dim)
+    assert torch.equal(dw, want)
+
+
 def test_bert_embedding_backward_without_atomics(hip):
     """ctclip_bert_embed_bwd (transformers BertEmbeddings backward): d(word) / d(position) / d(token type) against
     torch's index_add on the same inputs -- ids with many repeats (and one id used by every row of a sequence), on top of
