@@ -162,6 +162,8 @@ class _Hip:
                     conv.append(a)
             timed = self._timed.get(full)
             work = timed["work_fn"](*args) if timed is not None else None
+            if isinstance(work, dict):                       # which stream the launch goes to (the text tower has its own)
+                work = dict(work, stream=str(torch.cuda.current_stream().cuda_stream))
             if work is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

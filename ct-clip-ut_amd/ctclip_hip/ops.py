@@ -10,6 +10,7 @@ softmax statistics / losses / optimiser are f32.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -137,6 +138,15 @@ class ShadowPlan:
         self.sets.append(s_)
         self._all = None
 
+    def prime(self, epoch=None):
+        """Bring EVERY registered set up to date on the current stream if the weight epoch moved (what the first refresh() of a
+        step does).  Called before work is forked onto a second stream, so that no module refills another stream's shadows."""
+        epoch = _weight_epoch if epoch is None else epoch
+        if self.epoch_done != epoch and len(self.sets) > 1:
+            self.refresh(self.sets[0], epoch)
+        elif self.epoch_done != epoch:
+            self.epoch_done = epoch
+
     def refresh(self, s_, epoch):
         """Fill s_'s destinations now.  The first call after the weight epoch moved fills EVERY registered set with one launch
         (and marks them: `fresh_epoch`); later calls in the same epoch fill the one set."""
@@ -160,6 +170,45 @@ class ShadowPlan:
 
 
 PLAN = ShadowPlan()
+
+# ---------------------------------------------------------------------------------------------------
+# The text tower's stream.  BERT-base on batch x 128 tokens is ~150 kernels per pass that each fill a fraction of the chip (its
+# GEMMs have 48 row tiles); run next to the image tower instead of in front of it they disappear into the image tower's tails:
+# 413 -> 405 ms per 96-pair step.  models/ctclip.py forks it in forward; autograd runs the backward of those nodes on the same
+# stream by its own rule; everything that reads what the other stream wrote joins first (join_side_streams: the trainer after
+# backward, HipAdam.zero_grad / step, GradSync before a collective).  CTCLIP_TEXT_STREAM=0 keeps one stream.
+# ---------------------------------------------------------------------------------------------------
+_text_stream = {"on": os.environ.get("CTCLIP_TEXT_STREAM", "1") != "0", "side": {}, "main": {}}
+
+
+def fork_text_stream(device):
+    """-> (main, side) streams for a forward that is about to run the text tower on `side`, or None when switched off.  Every
+    weight shadow is refilled on the main stream first, so that no module refills another stream's operands."""
+    if not _text_stream["on"] or device.type != "cuda":
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    side = _text_stream["side"].get(idx)
+    if side is None:
+        side = _text_stream["side"][idx] = torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream(device)
+    if main == side:
+        return None
+    _text_stream["main"][idx] = main
+    PLAN.prime()
+    side.wait_stream(main)
+    return main, side
+
+
+def join_side_streams():
+    """The current stream waits for everything issued so far on the text stream AND on the stream it was forked from (their
+    backward kernels accumulate into one gradient arena in place)."""
+    if not _text_stream["side"]:
+        return
+    cur = torch.cuda.current_stream()
+    for table in (_text_stream["side"], _text_stream["main"]):
+        st = table.get(cur.device.index)
+        if st is not None and st != cur:
+            cur.wait_stream(st)
 
 
 def pad8(n: int) -> int:

@@ -129,6 +129,7 @@ class HipAdam(torch.optim.Optimizer):
             self._build()
         for sync in self._grad_listeners:
             sync.reset()
+        ops.join_side_streams()                              # a backward may still be accumulating on the text stream
         for a in self._arenas:
             if a is not None:
                 a["g"].zero_()
@@ -141,6 +142,7 @@ class HipAdam(torch.optim.Optimizer):
         if not self._built:
             self._build()
         self._bind_grads(adopt=True)
+        ops.join_side_streams()                              # gradients of the text tower were accumulated on its own stream
         if not self._arenas or not next(a for a in self._arenas if a is not None)["p"].is_cuda:
             raise RuntimeError("HipAdam.step: parameters are not on a HIP device; the optimiser step runs as HIP kernels "
                                "and has no CPU fallback")
@@ -374,6 +376,7 @@ class GradSync:
     def _launch(self, b):
         chunk = self._flat(b)
         if chunk.is_cuda and dist.get_backend(self.group) == "nccl":
+            ops.join_side_streams()                          # the bucket may hold gradients written on the text stream and on the main one
             side = ops.side_stream_for_collectives()
             if side is None:
                 b["handle"] = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)

@@ -2,6 +2,8 @@
 (src/models/ctclip.py:10-129): same constructor, attributes, forward 5-tuple and state-dict keys."""
 from pathlib import Path
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -71,8 +73,20 @@ class CTCLIP(nn.Module):
         return tt(**text_inputs).last_hidden_state[:, 0, :]
 
     def forward(self, text_inputs, image_inputs, text_embeds=None):
-        text_output = self.encode_text(text_inputs) if text_inputs else text_embeds          # ctclip.py:107
+        fork = ops.fork_text_stream(image_inputs.device) if text_inputs else None
+        if fork is not None:
+            # the text tower on its own stream next to the image tower (ops.fork_text_stream); its latent follows on that stream
+            main, side = fork
+            with torch.cuda.stream(side):
+                text_output = self.encode_text(text_inputs)
+                text_latents = ops.LinearF32Fn.apply(text_output.to(F32), self.to_text_latent.weight, None, False)  # :115
+                text_latents = ops.RowNormFn.apply(text_latents)                                  # :119
+        else:
+            text_output = self.encode_text(text_inputs) if text_inputs else text_embeds      # ctclip.py:107
         image_tokens = self.visual_transformer(image_inputs)                                  # :110
+        if fork is not None:
+            main.wait_stream(side)
+            text_latents.record_stream(main)
         if not image_tokens.is_cuda:
             raise RuntimeError("CTCLIP: MI355X HIP path only (no CPU fallback)")
         wv = self.to_visual_latent.weight
@@ -86,8 +100,9 @@ class CTCLIP(nn.Module):
             return S
         wv16 = self._shadow.get_set("wv", (wv,), make)
         image_latents = ops.VisualLatentFn.apply(image_tokens.to(F32), wv, wv16)              # :111-112,116
-        text_latents = ops.LinearF32Fn.apply(text_output.to(F32), self.to_text_latent.weight, None, False)  # :115
-        text_latents = ops.RowNormFn.apply(text_latents)                                      # :119
+        if fork is None:
+            text_latents = ops.LinearF32Fn.apply(text_output.to(F32), self.to_text_latent.weight, None, False)  # :115
+            text_latents = ops.RowNormFn.apply(text_latents)                                  # :119
         image_latents = ops.RowNormFn.apply(image_latents)                                    # :120
         if self.gather_negatives and dist.is_available() and dist.is_initialized():
             # :123-124 as ONE collective: the reference gathers text then image latents with two all_gathers; both are

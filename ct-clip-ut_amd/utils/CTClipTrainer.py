@@ -176,6 +176,7 @@ class CTClipTrainer(nn.Module):
         sim_matrix, *_ = self.model(text_tokens, images)
         loss = self.loss_function(sim_matrix)
         loss.backward()
+        ops.join_side_streams()
         self.grad_sync.all_reduce_grads()
         self.optim.step(max_grad_norm=self.max_grad_norm if self.max_grad_norm else None)
         vq = getattr(getattr(self.model, "visual_transformer", None), "vq", None)
