@@ -183,3 +183,39 @@ def test_deterministic_mode_makes_the_training_step_bitwise_reproducible(tmp_pat
         print(f"  two runs and a resumed run of two training steps: bit-identical (losses {la})")
     finally:
         torch.use_deterministic_algorithms(was)
+
+
+def test_text_tower_on_its_own_stream_changes_no_bit(tmp_path):
+    """CTCLIP.forward runs the text tower on a second HIP stream next to the image tower (ops.fork_text_stream) and its backward
+    follows there; the optimiser joins the streams.  Only the ORDER in time of independent kernels changes: under deterministic
+    algorithms two training steps end in the same bits with the fork on and off -- losses, weights, codebook, Adam moments."""
+    from ctclip_hip import ops
+    from utils.CTClipTrainer import CTClipTrainer
+    was_det, was_on = torch.are_deterministic_algorithms_enabled(), ops._text_stream["on"]
+    torch.use_deterministic_algorithms(True)
+    try:
+        def run(fork):
+            ops._text_stream["on"] = fork
+            clip, data, _ = _config1()
+            trainer = CTClipTrainer(clip, batch_size=4, results_folder=None)
+            losses = [trainer.train_step((vol, txt)) for txt, vol in data]
+            torch.cuda.synchronize()
+            state = {k: v.detach().clone() for k, v in trainer.model.state_dict().items()}
+            moments = [None if a is None else (a["m"].clone(), a["v"].clone()) for a in trainer.optim._arenas]
+            trainer.grad_sync.close()
+            return losses, state, moments
+
+        la, sa, ma = run(False)
+        lb, sb, mb = run(True)
+        assert ops._text_stream["side"], "the fork never ran"
+        assert la == lb, (la, lb)
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), f"{k} differs with the text tower on its own stream"
+        for x, y in zip(ma, mb):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), "Adam moments differ"
+        print(f"  one stream vs text tower on its own stream: bit-identical after two steps (losses {la})")
+    finally:
+        ops._text_stream["on"] = was_on
+        torch.use_deterministic_algorithms(was_det)
