@@ -477,6 +477,24 @@ def cpu_baseline(model, depth, size, L, vocab, reps=3):
                       f"up to {reps} timed repetitions, median ({spent[0]:.1f} s of timed CPU work), layers multiplied out to 4+4+12 -> "
                       f"{total:.1f} s per pair-step"),
            "parts_s": {k: round(v, 3) for k, v in parts.items()}}
+    # the composition checked against ONE whole production-shape training step through the oracle (forward, InfoNCE, backward, clip,
+    # Adam: O.train_steps, what BASELINE.md section 2 describes), two pairs so that the contrastive loss is not degenerate -- bounded:
+    # skipped on a host where the stages say it would take more than ~40 s
+    if 2.0 * total <= 40.0:
+        try:
+            vol2, txt2 = synthetic_batch(2, depth, size, L, vocab, torch.device("cpu"), 1, dtype=torch.float32)
+            frozen = [k for k in st if k.endswith(".beta") or "vq._codebook." in k or not st[k].is_floating_point()]
+            ocfg = dict(VIT, text_layers=TEXT["num_hidden_layers"], text_heads=TEXT["num_attention_heads"])
+            t0 = time.time()
+            losses, _, _ = O.train_steps(st, [(txt2, vol2)], ocfg, lr=1.25e-5, max_grad_norm=0.5, frozen=frozen)
+            e2e = time.time() - t0
+            log(f"one whole production step, 2 pairs, end to end: {e2e:.1f} s = {2.0 / e2e:.4f} pairs/s (composed stages: {2.0 * total:.1f} s)")
+            out["end_to_end_step"] = {"pairs": 2, "seconds": e2e, "value": 2.0 / e2e, "unit": "pairs/s", "loss": losses[-1],
+                                      "composed_seconds_for_the_same": 2.0 * total,
+                                      "what": "one whole training step of the oracle at the production shape (no warm-up, no repetition)"}
+        except Exception as exc:                              # a host without the memory for it keeps the composed figure
+            log(f"end-to-end production step skipped: {exc!r}")
+            out["end_to_end_step"] = {"error": repr(exc)}
     out["config1"] = cpu_config1(O, reps, log)
     return out
 
