@@ -662,8 +662,6 @@ def main():
     # steps with that overlap switched off give the family's stand-alone rate, and time the other kernels north_star names
     # (tubelet patch-embed, spatial attention, VQ search) undisturbed.
     from ctclip_hip import ops as _ops
-    side_was = _ops._side["on"]
-    _ops._side["on"] = False
     text_was = _ops._text_stream["on"]
     _ops._text_stream["on"] = False
     arm(gemm_fns)
@@ -674,7 +672,6 @@ def main():
     sync()
     timed2 = hip.stop_timing()
     alone = family(timed2)
-    _ops._side["on"] = side_was
     _ops._text_stream["on"] = text_was
     # what the HIP-event pairs around the GEMM launches cost the timed region: the same steps once more with no timing armed
     sync()
@@ -782,7 +779,6 @@ def main():
                          "frac_of_measured_mfma": gemm_tflops / peaks["mfma_bf16_tflops"],
                          "frac_of_measured_mfma_without_stream_overlap": alone_tflops / peaks["mfma_bf16_tflops"],
                          "kernels": kernels,
-                         "side_stream": bool(side_was),
                          "text_stream": {"on": bool(text_was),
                                          "launches_per_step": (timing_all["launches"] - timing["launches"]) / args.steps,
                                          "gflops_per_step": (timing_all["flops"] - timing["flops"]) / args.steps / 1e9,
@@ -796,9 +792,9 @@ def main():
                                           "overhead_frac": (dt - dt_plain) / dt_plain,
                                           "what": "the timed region records a HIP-event pair around each of the step's ~294 GEMM "
                                                   "launches; the same steps re-run with nothing armed show what that costs"},
-                         "note": "achieved: HIP-event durations inside the timed region of the launches on the step's own stream (the text tower's are in text_stream; CTCLIP_WGRAD_STREAM=1 "
-                                 "puts the weight-gradient GEMMs on a second one); *_without_stream_overlap and `kernels`: same "
-                                 "launches, two extra untimed steps on one stream; flops counted on the unpadded GEGLU width 1365"},
+                         "note": "achieved: HIP-event durations inside the timed region of the launches on the step's own stream (the text tower's, "
+                                 "on their own stream, are in text_stream); *_without_stream_overlap and `kernels`: every launch, two extra "
+                                 "untimed steps on one stream; flops counted on the unpadded GEGLU width 1365"},
         }
         if not args.no_attribution and not args.lean and world == 1 and not args.small:
             del batch

@@ -268,59 +268,9 @@ def _splits_for(m_out: int, n_out: int, k: int) -> int:
     return max(1, min(nk, (1024 + tiles - 1) // tiles))
 
 
-# ---- weight gradients on a second HIP stream (optional, off by default) -----------------------------------------------
-# Weight-gradient GEMMs are off the backward's critical path (their results only land in `.grad`); issued on a side stream
-# they share the CUs with the kernels that follow them on the main stream.  The side stream waits for an event recorded
-# at the issue point (inputs are complete), the operands are pinned for it (`record_stream`), and the main stream re-joins
-# it in a callback queued to the end of the running backward pass, so `.grad` is complete whenever `backward()` returns.
-# Measured on the MI355X (same box, interleaved runs of the full step): 319.2 / 317.4 ms with the side stream, 316.4 /
-# 318.5 ms without -- every kernel of this step fills the chip by itself, so co-scheduling buys nothing and only stretches
-# each launch.  CTCLIP_WGRAD_STREAM=1 turns it on.
-import os as _os
-
-_side = {"on": _os.environ.get("CTCLIP_WGRAD_STREAM", "0") != "0", "stream": None, "dirty": False, "queued": False}
-
-
-def join_side_stream() -> None:
-    _side["queued"] = False
-    if _side["dirty"]:
-        torch.cuda.current_stream().wait_stream(_side["stream"])
-        _side["dirty"] = False
-
-
-def on_side_stream(fn, *pinned):
-    """Run fn() (kernel launches only) on the weight-gradient stream, ordered after everything issued so far."""
-    if not _side["on"] or not pinned[0].is_cuda:
-        return fn()
-    if _side["stream"] is None:
-        _side["stream"] = torch.cuda.Stream()
-    s = _side["stream"]
-    ev = torch.cuda.current_stream().record_event()
-    with torch.cuda.stream(s):
-        s.wait_event(ev)
-        r = fn()
-    for t in pinned:
-        t.record_stream(s)
-    _side["dirty"] = True
-    if not _side["queued"]:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
-            _side["queued"] = True
-        except RuntimeError:                     # not inside a backward pass: join right away
-            join_side_stream()
-    return r
-
-
-def side_stream_for_collectives():
-    """The weight-gradient stream, for GradSync: a collective issued from it (after it has been made to wait for the main
-    stream) orders after the gradient kernels of BOTH streams.  None when everything runs on one stream."""
-    if not _side["on"] or not torch.cuda.is_available():
-        return None
-    if _side["stream"] is None:
-        _side["stream"] = torch.cuda.Stream()
-    return _side["stream"]
-
-
+# (Rounds 1-3 could issue the weight-gradient GEMMs on a second stream, CTCLIP_WGRAD_STREAM=1: measured equal in round 3 and 2 %
+# slower in round 4 -- 406 vs 397 ms, full-chip kernels only stretch each other -- and removed.  The text tower, whose kernels do
+# NOT fill the chip, is what runs on a second stream: fork_text_stream above.)
 def _wgrad_now(dy16, x16, n_feat, k_feat, tokens, out):
     hip.gemm_bf16(dy16, x16, out, None, None, n_feat, k_feat, tokens, dy16.stride(0), x16.stride(0), out.stride(0), 0,
                   0, 0, 1, _splits_for(n_feat, k_feat, tokens), 1, 1.0, 0)
@@ -330,26 +280,18 @@ def _wgrad_now(dy16, x16, n_feat, k_feat, tokens, out):
 def wgrad(dy16, x16, n_feat, k_feat, tokens, out=None):
     """dW[n_feat,k_feat] (+)= dy^T x over `tokens` rows; f32 atomics (out must be zero or a running sum).
 
-    With `out` given (a `.grad` slot) the product is fire-and-forget on the side stream; without, the caller consumes the
-    result right away and it stays on the current stream."""
+    `out` given: a `.grad` slot that is accumulated into."""
     if out is None:
         out = torch.zeros(n_feat, k_feat, dtype=F32, device=dy16.device)
-        return _wgrad_now(dy16, x16, n_feat, k_feat, tokens, out)
-    return on_side_stream(lambda: _wgrad_now(dy16, x16, n_feat, k_feat, tokens, out), dy16, x16, out)
+    return _wgrad_now(dy16, x16, n_feat, k_feat, tokens, out)
 
 def colsum(x2d, out=None):
-    """out[c] (+)= sum_r x[r, c]  (bias gradients); x f32 or bf16.  With `out` given (a `.grad` slot) the sum is
-    fire-and-forget on the weight-gradient stream, like wgrad()."""
+    """out[c] (+)= sum_r x[r, c]  (bias gradients); x f32 or bf16.  `out` given: a `.grad` slot that is accumulated into."""
     rows, cols = x2d.shape
     if out is None:
         out = torch.zeros(cols, dtype=F32, device=x2d.device)
-        hip.colsum_accum(x2d, int(x2d.dtype == BF16), rows, cols, x2d.stride(0), out)
-        return out
-
-    def run():
-        hip.colsum_accum(x2d, int(x2d.dtype == BF16), rows, cols, x2d.stride(0), out)
-        return out
-    return on_side_stream(run, x2d, out)
+    hip.colsum_accum(x2d, int(x2d.dtype == BF16), rows, cols, x2d.stride(0), out)
+    return out
 
 
 def dgrad(dy16, w16, tokens, n_feat, k_feat, *, out_dtype=F32, resid=None, wT16=None):
@@ -552,13 +494,10 @@ class PegFn(Function):
         gb, db_direct = grad_slot(p_b, note=False)
         if dw_direct and db_direct:
             _issued.extend(q for q in (p_w, p_b) if getattr(q, "_ctclip_sync", None) is not None)
-            # HBM-bound and off the critical path: on the side stream it shares the chip with the matrix-bound GEMMs of the
-            # layer whose backward comes next; the tap-major result is folded into the [d,1,3,3,3] gradient there too
-            def peg_wgrad():
-                dw27 = torch.zeros(27, d, dtype=F32, device=dy.device)
-                hip.peg_bwd_weight(dyc, xc, dw27, gb, b, t, h, w, d)
-                gw.view(d, 27).add_(dw27.t())
-            on_side_stream(peg_wgrad, dyc, xc, gw, gb)
+            # the tap-major result is folded into the [d,1,3,3,3] gradient in place
+            dw27 = torch.zeros(27, d, dtype=F32, device=dy.device)
+            hip.peg_bwd_weight(dyc, xc, dw27, gb, b, t, h, w, d)
+            gw.view(d, 27).add_(dw27.t())
             return dx, None, None, None, None
         dw27 = torch.zeros(27, d, dtype=F32, device=dy.device)
         db = torch.zeros(d, dtype=F32, device=dy.device)
@@ -855,7 +794,7 @@ class FeedForwardFn(Function):
         def ff1_wgrad():
             gw1p = wgrad(dh, n2, 2 * Ip, dim, M)                   # rows in the interleaved [val | gate] block order
             hip.geglu_wgrad_unblock(gw1p, gw1, I, GEGLU_BLOCK, dim)    # += value rows 0..I-1, gate rows I..2I-1 of the reference weight
-        on_side_stream(ff1_wgrad, dh, n2, gw1)
+        ff1_wgrad()
         dx = torch.empty(M, dim, dtype=F32, device=dy.device)
         dx16 = torch.empty(M, dim, dtype=BF16, device=dy.device)
         hip.layernorm_bwd_bf16(dn2, x2, ln_w, mean, rstd, dy2 if ctx.residual else None, None, dx, dx16, glw, glb, M, dim)
@@ -994,7 +933,7 @@ class SwapMiddleFn(Function):
 
 # Code groups of the VQ sweep (csrc/gemm3.hip, "CODE GROUPS"): measured at 64 / 88 pairs (profiles/r03_vq_code_groups.txt) the
 # split lowers the fabric traffic by only 30 % (33.4 -> 23.5 GB per launch) and costs 2 - 14 % of time: one group stays the default.
-VQ_CODE_GROUPS = int(_os.environ.get("CTCLIP_VQ_CODE_GROUPS", "1"))
+VQ_CODE_GROUPS = int(os.environ.get("CTCLIP_VQ_CODE_GROUPS", "1"))
 
 # ---------------------------------------------------------------------------------------------------
 # VQ (cosine-sim codebook, straight-through)            ctvit.py:117-118

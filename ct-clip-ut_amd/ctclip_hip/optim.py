@@ -377,15 +377,7 @@ class GradSync:
         chunk = self._flat(b)
         if chunk.is_cuda and dist.get_backend(self.group) == "nccl":
             ops.join_side_streams()                          # the bucket may hold gradients written on the text stream and on the main one
-            side = ops.side_stream_for_collectives()
-            if side is None:
-                b["handle"] = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            else:
-                # gradient kernels were issued on the main AND the side stream: side waits for main's tail, the
-                # collective is issued from side, so RCCL's stream orders after both
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    b["handle"] = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            b["handle"] = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         else:                                                # gloo: no AVG
             b["handle"] = (dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk)
 

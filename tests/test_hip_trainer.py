@@ -96,16 +96,15 @@ def test_rccl_branches_run_at_world_size_one():
         state_after_two = {k: v.detach().clone() for k, v in clip2.state_dict().items()}
         assert sync._bucket_of and all(b["handle"] is None for b in sync._buckets)
         assert tr2.model.visual_transformer.vq._pending_ema is None      # the background codebook reduce was joined
-        # the optional weight-gradient stream: collectives are then issued from it (ops.side_stream_for_collectives)
-        side_was = ops._side["on"]
-        ops._side["on"] = True
+        # one more step, with the text tower forced onto ONE stream: the collectives leave exactly once either way
+        text_was = ops._text_stream["on"]
+        ops._text_stream["on"] = False
         try:
             n0 = len(launched)
             extra_loss = tr2.train_step((data2[0][1], data2[0][0]))
             assert len(launched) - n0 == len(sync._buckets) and math.isfinite(extra_loss)
-            assert ops.side_stream_for_collectives() is not None
         finally:
-            ops._side["on"] = side_was
+            ops._text_stream["on"] = text_was
         clip2.load_state_dict(state_after_two)                            # the comparison below is about the two default steps
         avg = tr2.avg_device_loss(losses2[-1])
         assert abs(avg - losses2[-1]) < 1e-6
