@@ -82,15 +82,24 @@ def pmc_traffic(args):
         except ValueError:
             continue
         everything += float(f[1]) * float(f[4]) * 1e6
-        if name.startswith(("gemm3_kernel", "gemm4_kernel", "gemm2_kernel", "gemm_bf16_kernel")):
+        if name.startswith(GEMM_FAMILY_KERNELS):
             launches += float(f[1])
             total += float(f[1]) * float(f[4]) * 1e6
     rel = os.path.relpath(path, ROOT)
-    fam = {"traffic": (total / launches) if launches else None, "traffic_unit": "bytes per launch (mean over the family)",
+    fam = {"traffic": (total / launches) if launches else None,
+           "traffic_unit": "bytes per launch (mean over EVERY launch of the family's kernels in a step, both streams)",
            "traffic_source": f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
     if steps_profiled:
         per["__step_total__"] = everything / steps_profiled
+        fam["traffic_per_step"] = total / steps_profiled
+        fam["traffic_launches_per_step"] = launches / steps_profiled
     return fam, per
+
+
+# kernels behind ctclip_gemm_bf16 / _geglu / _geglu_bwd / _headmajor / _lnbwd (rocprofv3 names without the namespace): the family
+# `roofline` is reported on -- gemm3 (8 waves x 128 x 64) and gemm5 (4 waves x 128 x 128) for the k-major products, gemm4 for the
+# weight gradients, gemm2 / gemm_bf16 for small grids
+GEMM_FAMILY_KERNELS = ("gemm3_kernel", "gemm5_kernel", "gemm4_kernel", "gemm2_kernel", "gemm_bf16_kernel")
 
 
 PEAK_HBM_GBPS = 8000.0         # MI355X HBM3E (guides/MI355X_MICROARCH.md; ~6300 achievable by a float4 copy)
@@ -525,16 +534,42 @@ def cpu_config1(O, reps, log):
             "sample": f"two full training steps x {reps} repetitions after one warm-up, 4 pairs per step", "loss": losses[-1]}
 
 
+def visible_gpus():
+    """GPUs this process would see, WITHOUT the HIP runtime (the parent of self_launch must not initialise it before it starts
+    its ranks): KFD topology nodes with a non-zero simd_count, cut by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when one is set.  None when sysfs says nothing (then the ranks themselves report a missing device)."""
+    import glob
+    n = 0
+    paths = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not paths:
+        return None
+    for p in paths:
+        try:
+            for line in open(p):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(ids))
+    return n
+
+
 def self_launch(n):
     """`python bench.py --gpus N` from a plain shell (no RANK / WORLD_SIZE): start the N ranks the way the reference gets them
     from `accelerate launch` (src/utils/CTClipTrainer.py:62-69) -- one process per GPU through torch.distributed.run on
     127.0.0.1 -- relay rank 0's JSON line (the children inherit this stdout) and return their exit code.  This parent never
-    touches HIP: it only counts devices (which does not initialise the runtime on this image) and waits."""
+    touches HIP or torch.cuda: the device count for the error message is read from sysfs (visible_gpus), the ranks are fresh
+    child processes (subprocess, never an exec of this one)."""
     import socket
     import subprocess
     backend = os.environ.get("CTCLIP_DIST_BACKEND", "nccl")
-    have = torch.cuda.device_count()
-    if backend == "nccl" and have < n:
+    have = visible_gpus()
+    if backend == "nccl" and have is not None and have < n:
         print(f"bench.py: --gpus {n} but {have} device(s) visible (RCCL needs one device per rank; "
               "CTCLIP_DIST_BACKEND=gloo rehearses several ranks on one)", file=sys.stderr)
         return 2
@@ -691,6 +726,12 @@ def main():
         pairs = args.batch * world * args.steps
         fam_traffic, per_kernel_traffic = pmc_traffic(args)
         peaks = measured_peaks(hip, dev)
+        # counter traffic and algorithmic bytes over the SAME launch set: every launch of the family's kernels in one step, on
+        # both streams (the PMC passes cannot tell streams apart) -- per step, and their ratio
+        traffic_vs_alg = {"algorithmic_bytes_per_step_all_launches": timing_all["bytes"] / args.steps,
+                          "launches_per_step_all": timing_all["launches"] / args.steps}
+        if fam_traffic.get("traffic_per_step"):
+            traffic_vs_alg["traffic_over_algorithmic"] = fam_traffic["traffic_per_step"] / (timing_all["bytes"] / args.steps)
         gemm_tflops = timing["flops"] / (timing["total_ms"] * 1e-3) / 1e12 if timing["total_ms"] > 0 else 0.0
         alone_tflops = alone["flops"] / (alone["total_ms"] * 1e-3) / 1e12 if alone["total_ms"] > 0 else 0.0
         kernels = {}
@@ -755,14 +796,17 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "text_len": args.text_len,
                        "negatives": "local" if args.local_negatives or world == 1 else "global (all-gather)",
                        "parallelism": f"dp{world}", "peak_hbm_gib": round(peak_mem, 1), "final_loss": float(loss)},
-            "roofline": {"kernel": "ctclip_gemm_bf16 family (gemm3_kernel for the k-major products incl. the fused GEGLU epilogues, "
-                                   "gemm4_kernel, the same tile with transposed operands, for weight gradients, gemm2/gemm_bf16 kernels for small grids)",
+            "roofline": {"kernel": "ctclip_gemm_bf16 family (gemm3_kernel: 8 waves x 128 x 64, the k-major products incl. FF2 dgrad + GEGLU', the "
+                                   "head-major and LayerNorm-backward epilogues; gemm5_kernel: one wave per SIMD, 4 x 128 x 128, FF1 + GEGLU and "
+                                   "N >= 2048; gemm4_kernel: the gemm3 tile with transposed operands, weight gradients; gemm2 / gemm_bf16 "
+                                   "kernels for small grids)",
                          "bound": "mfma", "achieved": gemm_tflops,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_BF16_TFLOPS,
-                         **fam_traffic, "launches_per_step": timing["launches"] / args.steps,
+                         **fam_traffic, **traffic_vs_alg, "launches_per_step": timing["launches"] / args.steps,
                          "gemm_ms_per_step": timing["total_ms"] / args.steps,
                          "algorithmic_flops_per_step": timing["flops"] / args.steps,
-                         "algorithmic_bytes_per_launch": timing["bytes"] / max(1, timing["launches"]),
+                         "algorithmic_bytes_per_launch": timing_all["bytes"] / max(1, timing_all["launches"]),
+                         "algorithmic_bytes_per_launch_main_stream": timing["bytes"] / max(1, timing["launches"]),
                          "achieved_without_stream_overlap": alone_tflops,
                          "frac_without_stream_overlap": alone_tflops / PEAK_BF16_TFLOPS,
                          "gemm_ms_per_step_without_stream_overlap": alone["total_ms"] / extra,

@@ -9,7 +9,7 @@ typedef uint16_t bf16_t;  // raw bfloat16 storage
 // Environment inputs.  The shipped library reads exactly two variables, both TEST HOOKS documented in include/ctclip_hip.h:
 //   CTCLIP_GEMM_V2_ALL    lower the size gates of the pipelined GEMM kernels, so the test-suite reaches every kernel with
 //                         small shapes;
-//   CTCLIP_ATTN_SP_CHUNK  sequences per workgroup of the sequence-persistent attention kernels (ragged-chunk tests).
+//   CTCLIP_ATTN_SP_CHUNK  sequences per workgroup of the wave-per-sequence attention kernels (ragged-chunk tests).
 // A/B switches and timing ablations of the development rounds exist only in builds made with -DCTCLIP_TUNING_KNOBS
 // (CTCLIP_EXTRA_HIPCC_FLAGS of ctclip_hip/build.py, which writes libctclip_hip_diag.so next to the product library).
 #include <stdlib.h>
@@ -30,6 +30,31 @@ constexpr long kPartialsFloats = 1L << 21;
 // out[c] += sum_{part < nparts, in index order} partials[part * ld + c]  (tail.hip; the second stage of the two-stage
 // reductions: no atomics, bitwise reproducible)
 int ctclip_reduce_partials(const float* partials, int nparts, long ld, int width, float* out, hipStream_t st);
+
+// Per-DEVICE process state, all of it idempotent: the CU count (rounded down to a multiple of 8: a persistent workgroup's tiles
+// then stay on one XCD's run) and "the dynamic-LDS limit of this kernel was raised" -- kept per device id, so that a process which
+// drives several devices through this library gets the attribute on each of them.
+inline int ctclip_dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+inline int ctclip_cu_count8() {
+  static int n[64];
+  const int d = ctclip_dev();
+  if (!n[d]) {
+    int v = 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+    n[d] = v >= 8 ? (v / 8) * 8 : v;
+  }
+  return n[d];
+}
+#define CTCLIP_LDS_LIMIT_ONCE(fn, bytes)                                                                              \
+  do {                                                                                                                \
+    static unsigned long long done_ = 0;                                                                              \
+    const int d_ = ctclip_dev();                                                                                      \
+    if (!((done_ >> d_) & 1ull)) {                                                                                    \
+      hipError_t e_ = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+      if (e_ != hipSuccess) return (int)e_;                                                                           \
+      done_ |= 1ull << d_;                                                                                            \
+    }                                                                                                                 \
+  } while (0)
 
 #define CTCLIP_CHECK_LAUNCH() \
   do {                        \

@@ -431,9 +431,13 @@ int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* b
 int ctclip_gemm5_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                         long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
                         int hm_n, int hm_heads, hipStream_t st);
+bool ctclip_gemm5_eligible(const void* C, const float* bias, const float* resid, int N, int K, long ldc, long ldr, int c_fp32,
+                           int act);
 int ctclip_gemm3_launch_ln(const void* A, const void* B, float* C, void* C16, const float* resid, int M, int N, int K, long lda,
                            long ldb, long ldc, long ldc16, long ldr, const void* xhat, long ldx, const float* c1, const float* c2,
                            hipStream_t st);
+int ctclip_gemm3_launch_hn(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int hm_n,
+                           int hm_heads, const float* scale, float mult, float* inv, int norm_cols, hipStream_t st);
 int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int split_k,
                         float alpha, float* part, hipStream_t st);
 int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* part_idx, int M, int N, int K, long lda,
@@ -448,26 +452,25 @@ namespace {
 // (1831 vs 1931 us) and plain products with many column tiles (N >= 2048: FF1 forward 885 vs 830 TFLOP/s); gemm3 stays on
 // the N <= 1408 shapes (kv forward 765 vs 788, out-projection 508 vs 534) and on FF2 dgrad + GEGLU backward (1548 vs 1462 us).
 // K % 64 == 0 and K >= 192 (six K-steps: the ring fill).  Under the test hook CTCLIP_GEMM_V2_ALL every eligible product with
-// K >= 1024 goes to gemm5 so that the suite reaches all of its epilogues with small shapes (products with K < 1024 keep
-// exercising gemm3); CTCLIP_GEMM5_MINK (-DCTCLIP_TUNING_KNOBS builds: A/B runs) makes K >= that value the only criterion.
+// K >= 1024 goes to gemm5 IN ADDITION to the shapes a training run sends there, so that the suite reaches all of its epilogues
+// with small shapes (the other products with K < 1024 keep exercising gemm3); ctclip_gemm5_bf16 calls the kernel directly.
+// CTCLIP_GEMM5_MINK (-DCTCLIP_TUNING_KNOBS builds: A/B runs) makes K >= that value the only criterion.
 bool gemm5_takes(int N, int K, int act) {
   static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
   static const int mink = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM5_MINK"); return e ? atoi(e) : -1; }();
   if ((K % 64) != 0 || K < 192) return false;
   if (mink >= 0) return K >= mink;
-  if (v2_all) return K >= 1024;
+  if (v2_all && K >= 1024) return true;
   return act == 2 || (act <= 1 && N >= 2048);
 }
 // every k-major x k-major launch of the 256 x 256 LDS-DMA kernels goes through here: gemm5 when it takes the shape and the
-// output allows the 16-byte register epilogue (it returns hipErrorInvalidValue otherwise, before launching anything)
+// output allows the 16-byte register epilogue (asked BEFORE launching: an error of the launch itself is reported, not retried
+// on the other kernel)
 int launch_kk(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K, long lda,
               long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg, int hm_n, int hm_heads,
               hipStream_t st) {
-  if (gemm5_takes(N, K, act)) {
-    const int e = ctclip_gemm5_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, G, ldg, hm_n,
-                                      hm_heads, st);
-    if (e != (int)hipErrorInvalidValue) return e;
-  }
+  if (gemm5_takes(N, K, act) && ctclip_gemm5_eligible(C, bias, resid, N, K, ldc, ldr, c_fp32, act))
+    return ctclip_gemm5_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, G, ldg, hm_n, hm_heads, st);
   return ctclip_gemm3_launch_hm(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, G, ldg, hm_n, hm_heads, st);
 }
 }  // namespace
@@ -556,6 +559,18 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
   return finish(launch<0>(g, a_kmajor, b_kmajor, (hipStream_t)stream), g.split_k);
 }
 
+// The one-wave-per-SIMD kernel of gemm5.hip called directly (k-major x k-major; act 0 / 1 as ctclip_gemm_bf16, 2 = FF1 + GEGLU
+// with G = g [M, N / 2], 3 = FF2 data gradient + GEGLU backward with G = h): what the dispatcher does for the shapes
+// gemm5_takes() names, for any shape the kernel is eligible for.  hipErrorInvalidValue when it is not (K % 64, K < 192, outputs
+// that do not allow the 16-byte epilogue).
+int ctclip_gemm5_bf16(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K, long lda,
+                      long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true)) return (int)hipErrorInvalidValue;
+  return ctclip_gemm5_launch(A, B, C, bias, resid, M, N, K, lda, ldb, ldc, ldr, c_fp32, alpha, act, G, ldg, 0, 0,
+                             (hipStream_t)stream);
+}
+
 // C = A[M,K] B[N,K]^T written as bf16 in the HEAD-MAJOR layout of attention_hm.hip: [part][sequence][head][token][32]
 // with token = row % n_tokens, sequence = row / n_tokens, head = (col / 32) % heads, part = col / (32 heads).
 // Always the 256 x 256 LDS-DMA kernel of gemm3.hip (its epilogue has the form): K % 32 == 0, N % 64 == 0, M % n_tokens == 0.
@@ -565,6 +580,17 @@ int ctclip_gemm_bf16_headmajor(const void* A, const void* B, void* C, int M, int
   if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true) || (K % 32) || n_tokens <= 0) return (int)hipErrorInvalidValue;
   return launch_kk(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, N, 0, 0, 1.0f, 0, nullptr, 0, n_tokens, heads,
                    (hipStream_t)stream);
+}
+
+// C = A[M,K] B[N,K]^T with the per-head cosine normalisation of attention.py:146-153 applied in the epilogue to the heads of the
+// first norm_cols columns (include/ctclip_hip.h).  n_tokens > 0: head-major output as ctclip_gemm_bf16_headmajor; 0: row-major
+// [M, ldc].  Always the 256 x 256 LDS-DMA kernel of gemm3.hip (its register epilogue has the form).
+int ctclip_gemm_bf16_headnorm(const void* A, const void* B, void* C, float* inv_norm, const float* scale, int M, int N, int K,
+                              long lda, long ldb, long ldc, int n_tokens, int heads, int norm_cols, float mult, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (bad_layout(A, lda, K, true) || bad_layout(B, ldb, K, true) || (K % 32) || n_tokens < 0) return (int)hipErrorInvalidValue;
+  return ctclip_gemm3_launch_hn(A, B, C, M, N, K, lda, ldb, n_tokens > 0 ? N : ldc, n_tokens, heads, scale, mult, inv_norm,
+                                norm_cols, (hipStream_t)stream);
 }
 
 // dx = A[M,K] B[N,K]^T - c1[row] - xhat[row][col] c2[row] + resid  (f32, optional bf16 copy): a data-gradient product with the

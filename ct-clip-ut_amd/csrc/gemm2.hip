@@ -317,11 +317,7 @@ int ctclip_gemm2_launch(const void* A, const void* B, void* C, const float* bias
   dim3 grid(nblk), block(NT);
 #define G2_LAUNCH(AK, BK_)                                                                                          \
   do {                                                                                                              \
-    static bool attr_set = false;                                                                                   \
-    if (!attr_set) {                                                                                                \
-      hipFuncSetAttribute((const void*)gemm2_kernel<AK, BK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr_set = true;                                                                                              \
-    }                                                                                                               \
+    CTCLIP_LDS_LIMIT_ONCE((gemm2_kernel<AK, BK_>), lds);                                                            \
     hipLaunchKernelGGL((gemm2_kernel<AK, BK_>), grid, block, lds, st, g);                                           \
   } while (0)
   if (a_kmajor && b_kmajor) G2_LAUNCH(true, true);

@@ -135,7 +135,9 @@ __global__ __launch_bounds__(512, (TBN == 256 ? 2 : 4)) void gemm3_kernel(Args g
   locate(tile);
   issue_prologue();
   bool first = true, counted = false;
-  constexpr int NST = IM * (EPI == 0 ? 2 : EPI == 2 ? 3 : 4);   // 16-byte stores per wave of a full tile's register epilogue
+  // store instructions per wave of a full tile's register epilogue (EPI 5: at least 2 per row group, 3 in a normalised slab --
+  // the smaller count only makes the wait behind the epilogue stricter than it has to be)
+  constexpr int NST = IM * ((EPI == 0 || EPI == 5) ? 2 : EPI == 2 ? 3 : 4);
 
   // fragment addresses inside a stage: M rows 16 i + ml of this wave's rows, (permuted) N rows of its 64
   const int ml = lane & 15, q4 = lane >> 4;
@@ -441,17 +443,11 @@ int g3_launch(g3::Args& g, int epi, int c_fp32, hipStream_t st) {
   using namespace g3;
   const int M = g.M, N = g.N, K = g.K;
   static const int forced = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM3_BN"); return e ? atoi(e) : 0; }();
-  const int bn = (forced == 128 || forced == 256) ? forced : ((c_fp32 && K <= 256) ? 128 : 256);
+  const int bn = epi == 5 ? 256 : (forced == 128 || forced == 256) ? forced : ((c_fp32 && K <= 256) ? 128 : 256);
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + bn - 1) / bn;
 #define G3_LAUNCH(BN_, EPI_, LDS_)                                                                                        \
   do {                                                                                                                    \
-    static bool attr_set = false;                                                                                         \
-    if (!attr_set) {                                                                                                      \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm3_kernel<BN_, EPI_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)(LDS_));                                                                    \
-      if (e != hipSuccess) return (int)e;                                                                                 \
-      attr_set = true;                                                                                                    \
-    }                                                                                                                     \
+    CTCLIP_LDS_LIMIT_ONCE((gemm3_kernel<BN_, EPI_>), (LDS_));                                                             \
     hipLaunchKernelGGL((gemm3_kernel<BN_, EPI_>), dim3(grid), dim3(512), (LDS_), st, g);                                  \
   } while (0)
 #define G3_SHAPES(EPI_)                                                                                                   \
@@ -459,11 +455,7 @@ int g3_launch(g3::Args& g, int epi, int c_fp32, hipStream_t st) {
     if (bn == 256) G3_LAUNCH(256, EPI_, (size_t)G3_NS256 * (SUB + 256 * BK * 2)); /* 128 KiB: one workgroup per CU */           \
     else G3_LAUNCH(128, EPI_, (size_t)3 * (SUB + 128 * BK * 2));           /* 72 KiB: two workgroups per CU */           \
   } while (0)
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? (n / 8) * 8 : 256;                 // a multiple of 8 keeps a workgroup's tiles on one XCD's run
-  }();
+  const int cus = ctclip_cu_count8();                  // a multiple of 8 keeps a workgroup's tiles on one XCD's run
   const long total = (long)g.tiles_m * g.tiles_n;
   const long resident = (long)cus * (bn == 256 ? 1 : 2);
   static const bool persist = [] { const char* e = CTCLIP_KNOB("CTCLIP_GEMM3_PERSIST"); return !e || atoi(e) != 0; }();   // 0: one tile per workgroup (A/B)
@@ -472,6 +464,7 @@ int g3_launch(g3::Args& g, int epi, int c_fp32, hipStream_t st) {
   else if (epi == 1) G3_SHAPES(1);
   else if (epi == 2) G3_SHAPES(2);
   else if (epi == 3) G3_SHAPES(3);
+  else if (epi == 5) G3_LAUNCH(256, 5, (size_t)G3_NS256 * (SUB + 256 * BK * 2));   // bf16 output: always the 256 x 256 shape
   else G3_SHAPES(4);
 #undef G3_SHAPES
 #undef G3_LAUNCH
@@ -521,6 +514,29 @@ int ctclip_gemm3_launch_hm(const void* A, const void* B, void* C, const float* b
     g.hm_part = (long)M * hm_heads * 32;
   }
   return g3_launch(g, act >= 2 ? act : (c_fp32 ? 1 : 0), c_fp32, st);
+}
+
+// The bf16 product with the per-head cosine normalisation applied in the epilogue (gemm_tile.h, EPI 5): the heads (32 columns
+// each) of the first norm_cols columns leave normalised, scaled by scale[d] * mult, and their 1 / norm goes to inv [M, norm_cols /
+// 32]; hm_n > 0 writes the head-major layout as ctclip_gemm3_launch_hm does.  norm_cols % 64 == 0, N % 64 == 0, 16-byte aligned C.
+int ctclip_gemm3_launch_hn(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int hm_n,
+                           int hm_heads, const float* scale, float mult, float* inv, int norm_cols, hipStream_t st) {
+  using namespace g3;
+  if (!scale || !inv || norm_cols <= 0 || norm_cols > N || (norm_cols & 63) || (N & 63) || (((uintptr_t)C) & 15) || (ldc & 7) ||
+      (K % BK))
+    return (int)hipErrorInvalidValue;
+  if (hm_n > 0 && (hm_heads <= 0 || (M % hm_n) || (N / 32) % hm_heads || hm_n < 2 || (long)M * hm_n >= (1L << 32)))
+    return (int)hipErrorInvalidValue;
+  Args g{};
+  g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = 1.0f; g.direct = 1;
+  g.hn_scale = scale; g.hn_mult = mult; g.hn_inv = inv; g.hn_cols = norm_cols;
+  if (hm_n > 0) {
+    g.hm_n = hm_n; g.hm_heads = hm_heads;
+    g.hm_magic = (uint32_t)(((1ull << 32) + (unsigned long long)hm_n - 1) / (unsigned long long)hm_n);
+    g.hm_part = (long)M * hm_heads * 32;
+  }
+  return g3_launch(g, 5, 0, st);
 }
 
 // The f32 product with the LayerNorm backward applied in the epilogue (gemm_tile.h, EPI 4): C = A B^T - c1[row] - xhat c2[row]
@@ -574,12 +590,7 @@ int ctclip_vq_topk3_launch(const void* A, const void* B, float* part_val, int* p
   g.cgroups = cgroups; g.ttiles = 32 / cgroups; g.ntok_tiles = (N + 255) / 256;
   g.tiles_m = M / BM / cgroups; g.part_val = part_val; g.part_idx = part_idx;
   const size_t lds = (size_t)4 * 2 * SUB;          // 128 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)vq_topk3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  CTCLIP_LDS_LIMIT_ONCE(vq_topk3_kernel, lds);
   unsigned grid = (unsigned)g.ntok_tiles;
   if (cgroups > 1) {
     const int per_round = 8 * g.ttiles;                               // token tiles the eight XCDs take side by side

@@ -385,13 +385,8 @@ int ctclip_gemm4_launch(const void* A, const void* B, void* C, int M, int N, int
   g.alpha = alpha;
   g.part = g.split_k > 1 ? part : nullptr;
   const size_t lds = (size_t)NS * STAGE;           // 128 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm4_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  CTCLIP_LDS_LIMIT_ONCE(gemm4_kernel<true>, lds);
+  CTCLIP_LDS_LIMIT_ONCE(gemm4_kernel<false>, lds);
   static const bool mf32 = CTCLIP_KNOB("CTCLIP_GEMM4_MFMA32") != nullptr;
   if (mf32) hipLaunchKernelGGL(gemm4_kernel<false>, dim3(g.tiles_m * g.tiles_n * g.split_k), dim3(NT), lds, st, g);
   else hipLaunchKernelGGL(gemm4_kernel<true>, dim3(g.tiles_m * g.tiles_n * g.split_k), dim3(NT), lds, st, g);

@@ -234,6 +234,20 @@ __global__ __launch_bounds__(256) void gemm5_kernel(Args g) {
 
 }  // namespace g5
 
+// Does this kernel take the problem at all?  (K a whole number of k64 pairs and at least the ring fill; outputs that allow the
+// 16-byte register epilogue.)  The dispatcher asks BEFORE launching, so that an error code of the launch itself is never
+// mistaken for "not eligible".
+static bool g5_direct(const void* C, const float* bias, const float* resid, int N, long ldc, long ldr, int c_fp32, int act) {
+  return (act >= 2) ||
+         ((N & 7) == 0 && (((uintptr_t)C) & 15) == 0 && (ldc & (c_fp32 ? 3 : 7)) == 0 &&
+          (!bias || (((uintptr_t)bias) & 15) == 0) && (!resid || ((((uintptr_t)resid) & 15) == 0 && (ldr & 3) == 0)));
+}
+bool ctclip_gemm5_eligible(const void* C, const float* bias, const float* resid, int N, int K, long ldc, long ldr, int c_fp32,
+                           int act) {
+  using namespace g5;
+  return (K % (2 * BK)) == 0 && K / BK >= 6 && g5_direct(C, bias, resid, N, ldc, ldr, c_fp32, act);
+}
+
 // called by the dispatcher in gemm.hip: same contract as ctclip_gemm3_launch_hm
 int ctclip_gemm5_launch(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K,
                         long lda, long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg,
@@ -248,38 +262,25 @@ int ctclip_gemm5_launch(const void* A, const void* B, void* C, const float* bias
     return (int)hipErrorInvalidValue;
   if (act == 3 && (c_fp32 || bias || resid || !G || (N & 31) || (ldg & 7) || (((uintptr_t)G) & 15)))
     return (int)hipErrorInvalidValue;
-  if ((K % (2 * BK)) || K / BK < 6) return (int)hipErrorInvalidValue;
+  if (!ctclip_gemm5_eligible(C, bias, resid, N, K, ldc, ldr, c_fp32, act)) return (int)hipErrorInvalidValue;
   Args g{};
   g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C; g.bias = bias; g.resid = resid;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
   g.act = act; g.alpha = alpha; g.G = (bf16_t*)G; g.ldg = ldg;
-  g.direct = (act >= 2) ||
-             ((N & 7) == 0 && (((uintptr_t)C) & 15) == 0 && (ldc & (c_fp32 ? 3 : 7)) == 0 &&
-              (!bias || (((uintptr_t)bias) & 15) == 0) && (!resid || ((((uintptr_t)resid) & 15) == 0 && (ldr & 3) == 0)));
-  if (!g.direct) return (int)hipErrorInvalidValue;     // unaligned outputs stay on gemm3.hip (dispatcher)
+  g.direct = 1;                                        // (unaligned outputs stay on gemm3.hip: ctclip_gemm5_eligible)
   if (hm_n > 0) {
     g.hm_n = hm_n; g.hm_heads = hm_heads;
     g.hm_magic = (uint32_t)(((1ull << 32) + (unsigned long long)hm_n - 1) / (unsigned long long)hm_n);
     g.hm_part = (long)M * hm_heads * 32;
   }
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + 255) / 256;
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? (n / 8) * 8 : 256;                 // a multiple of 8 keeps a workgroup's tiles on one XCD's run
-  }();
+  const int cus = ctclip_cu_count8();                  // a multiple of 8 keeps a workgroup's tiles on one XCD's run
   const long total = (long)g.tiles_m * g.tiles_n;
   const int grid = (int)(total < cus ? total : cus);
   constexpr size_t lds = (size_t)G5_NS * 2 * SUB;
 #define G5_LAUNCH(EPI_)                                                                                                   \
   do {                                                                                                                    \
-    static bool attr_set = false;                                                                                         \
-    if (!attr_set) {                                                                                                      \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm5_kernel<EPI_, G5_NS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                         (int)lds);                                                                       \
-      if (e != hipSuccess) return (int)e;                                                                                 \
-      attr_set = true;                                                                                                    \
-    }                                                                                                                     \
+    CTCLIP_LDS_LIMIT_ONCE((gemm5_kernel<EPI_, G5_NS>), lds);                                                              \
     hipLaunchKernelGGL((gemm5_kernel<EPI_, G5_NS>), dim3(grid), dim3(256), lds, st, g);                                   \
   } while (0)
   const int epi = act >= 2 ? act : (c_fp32 ? 1 : 0);

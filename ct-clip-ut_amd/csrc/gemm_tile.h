@@ -32,6 +32,10 @@ struct Args {
   const bf16_t* xhat; long ldx;
   const float* c1; const float* c2;
   bf16_t* C16; long ldc16;
+  // EPI 5 (per-head cosine normalisation of the product, bf16 out, row-major or head-major): the heads of the first hn_cols
+  // columns (32 columns each) leave as  y = x / max(|x|, 1e-12) * hn_scale[d] * hn_mult  with 1 / max(|x|, 1e-12) stored in
+  // hn_inv[row][head] (hn_cols / 32 heads per row); the columns behind them are stored as they are (the v half of a kv product)
+  const float* hn_scale; float hn_mult; float* hn_inv; int hn_cols;
 };
 
 // [256 rows][32 k] bf16 tile, 64-byte rows, 16-byte chunks XOR-swizzled so that the 16 lanes of a ds_read_b128 phase hit 16
@@ -113,6 +117,18 @@ __device__ __forceinline__ uint4 f4_bits(float a, float b, float c, float d) {
   return make_uint4(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d));
 }
 
+// x + (x of lanes ^ 16) + (x of lanes ^ 32) + (x of lanes ^ 48): the four lanes (q4 = 0..3) that hold one row's pieces of a
+// 32-column head.  v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another, so with both
+// operands = x the two results are [r0 r0 r2 r2] and [r1 r1 r3 r3]; v_permlane32_swap does the same for the wave's halves.
+__device__ __forceinline__ float sum_over_q4(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const uint32_t v = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 #define G3_GLDS(gptr, ldsoff)                                                                                     \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                          \
                                    (__attribute__((address_space(3))) void*)(uintptr_t)(ldsoff), 16, 0, 0)
@@ -123,6 +139,7 @@ __device__ __forceinline__ uint4 f4_bits(float a, float b, float c, float d) {
 // GENERIC = false leaves out the element-wise path for unaligned outputs (the caller then only takes g.direct problems).
 // EPI: 0 plain -> bf16   1 plain -> f32   (both: alpha, bias, residual, erf-GELU when g.act == 1)   2 FF1 + GEGLU
 //      3 FF2 data gradient + GEGLU backward   4 the f32 form with the LayerNorm backward applied (Args::xhat, c1, c2)
+//      5 bf16 with the per-head cosine normalisation applied (Args::hn_*; attention.py:146-153)
 template <int EPI, int IM, int NJ, int J0, bool AHEAD, bool GENERIC = true>
 __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ], int rbase, int colw, int lane) {
   constexpr bool F32OUT = EPI == 1 || EPI == 4, LNB = EPI == 4;
@@ -263,6 +280,58 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
             bf16_t* hp = g.G + (long)row * g.ldg + (long)(c >> 5) * 64 + 32 * hsel + (c & 31);
             if (row < g.M) st16(hp, s0);
             if (row + 8 < g.M) st16(hp + 8 * g.ldg, s1);
+          }
+        }
+      }
+    } else if constexpr (EPI == 5) {
+      // q / k projection with the per-head cosine normalisation (attention.py:146-153): the slab is two heads; a lane holds 8 of
+      // a head's 32 columns for each of its rows, the other 24 sit in the lanes 16, 32 and 48 further -- sum of squares over the
+      // four, 1 / max(norm, 1e-12), the learned per-channel scale times `mult`, store.  Nothing of the raw projection is written.
+      const bool norm = colw < g.hn_cols;            // uniform over the slab (hn_cols % 64 == 0)
+      float sc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc[e] = norm ? g.hn_scale[8 * q4 + e] * g.hn_mult : 1.f;
+      const int hpr = g.hn_cols >> 5;                // normalised heads per row
+#pragma unroll
+      for (int i = 0; i < IM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        float v[2][8], inv[2] = {1.f, 1.f};
+        const int rowl = rbase + i * 16 + ml;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[h][e] = acc[i][J0 + 2 * h + (e >> 2)][e & 3] * g.alpha; ss = fmaf(v[h][e], v[h][e], ss); }
+          if (norm) {
+            ss = sum_over_q4(ss);
+            inv[h] = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[h][e] *= inv[h] * sc[e];
+          }
+        }
+        // lanes q4 = 0 / 1 of a row store the first / second head's 1 / norm: one store instruction per row group
+        if (norm && q4 < 2 && rowl < g.M && colw + 32 * q4 < g.N) g.hn_inv[(long)rowl * hpr + ((colw >> 5) + q4)] = q4 ? inv[1] : inv[0];
+        if (g.hm_n) {
+          if (rowl < g.M) {
+            const uint32_t sq = __umulhi((uint32_t)rowl, g.hm_magic), tok = (uint32_t)rowl - sq * (uint32_t)g.hm_n;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int col = colw + 32 * h + 8 * q4;
+              if (col < g.N) {
+                const int vh = col >> 5, part = vh / g.hm_heads, hh = vh - part * g.hm_heads;
+                st16((bf16_t*)g.C + (long)part * g.hm_part + ((long)(sq * g.hm_heads + hh) * g.hm_n + tok) * 32 + 8 * q4,
+                     pack8(v[h]));
+              }
+            }
+          }
+        } else {
+          uint4 s0, s1;
+          line_pair(pack8(v[0]), pack8(v[1]), upper, s0, s1);
+          const int col = colw + 32 * hsel + 8 * q4;
+          const int row = rbase + i * 16 + rsub;
+          if (col < g.N) {
+            if (row < g.M) st16((bf16_t*)g.C + (long)row * g.ldc + col, s0);
+            if (row + 8 < g.M) st16((bf16_t*)g.C + (long)(row + 8) * g.ldc + col, s1);
           }
         }
       }

@@ -284,6 +284,9 @@ __global__ __launch_bounds__(256) void headnorm_fwd_kernel(const bf16_t* __restr
 }
 
 // dx = inv * (du - u (u . du)),  u = x*inv,  du = dy * scale * mult ;  dscale[d] += sum dy * u * mult
+// x_normed: `x` is not the raw projection but the forward's OUTPUT y = u scale mult (the q / k GEMM normalised in its epilogue,
+// ctclip_gemm_bf16_headnorm, and nothing else of the projection was kept): u = y / (scale mult), the raw row is u / inv.  A
+// channel whose learned scale is exactly 0 has lost its u (y = 0): it gets u = 0, i.e. no gradient through that channel.
 // LNX (ctclip_headnorm_bwd_ln): the eight heads of a row are the 32 lanes of half a wave; besides dx the kernel writes the row
 // scaled by rstd and the two row constants of the LayerNorm backward that runs in the next GEMM's epilogue.
 struct HeadLnx { const float* rstd; const float* wbar; bf16_t* dxs; long lddxs; float* c1; float* c2; float inv_dim; };
@@ -292,13 +295,17 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restr
                                                            const float* __restrict__ inv_norm, const float* __restrict__ scale,
                                                            bf16_t* __restrict__ dx, float* __restrict__ partials,
                                                            long npairs, int H, long lddy, long ldx, long lddx, float mult,
-                                                           int x_hm, HeadLnx lx) {
+                                                           int x_hm, int x_normed, HeadLnx lx) {
   __shared__ float red[256 / LPH][LPH * 8 + 1];                      // [pair slot of the workgroup][d]
   const int D = LPH * 8;
   const int sub = threadIdx.x % LPH;
-  float acc[8];
+  float acc[8], rsc[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 8; ++i) {
+    acc[i] = 0.f;
+    const float sm = scale[sub * 8 + i] * mult;
+    rsc[i] = sm != 0.f ? 1.0f / sm : 0.f;
+  }
   const long stride = (long)gridDim.x * (256 / LPH);
   // every lane of an LPH group walks the same pair sequence, so the shuffles below stay convergent
   const long iters = (npairs + stride - 1) / stride;
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restr
     for (int i = 0; i < 4; ++i) {
       const float x0 = __uint_as_float(wx[i] << 16), x1 = __uint_as_float(wx[i] & 0xffff0000u);
       const float d0 = __uint_as_float(wd[i] << 16), d1 = __uint_as_float(wd[i] & 0xffff0000u);
-      u[2 * i] = x0 * inv; u[2 * i + 1] = x1 * inv;
+      u[2 * i] = x_normed ? x0 * rsc[2 * i] : x0 * inv; u[2 * i + 1] = x_normed ? x1 * rsc[2 * i + 1] : x1 * inv;
       du[2 * i] = d0 * scale[sub * 8 + 2 * i] * mult; du[2 * i + 1] = d1 * scale[sub * 8 + 2 * i + 1] * mult;
       acc[2 * i] += d0 * u[2 * i] * mult; acc[2 * i + 1] += d1 * u[2 * i + 1] * mult;
       dot += u[2 * i] * du[2 * i] + u[2 * i + 1] * du[2 * i + 1];
@@ -336,11 +343,13 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restr
     if constexpr (LNX) {
       // H * LPH == 32: the lanes of this row are an aligned group of 32
       const float rs = ok ? lx.rstd[row] : 0.f;
+      const float nrm = inv > 0.f ? 1.0f / inv : 0.f;                    // |raw row| (x_normed: the raw row is u |row|)
       float s1 = 0.f, s2 = 0.f, v[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         v[2 * i] = __uint_as_float(ow[i] << 16); v[2 * i + 1] = __uint_as_float(ow[i] & 0xffff0000u);     // dx as the GEMM will read it
-        const float x0 = __uint_as_float(wx[i] << 16), x1 = __uint_as_float(wx[i] & 0xffff0000u);
+        const float x0 = x_normed ? u[2 * i] * nrm : __uint_as_float(wx[i] << 16);
+        const float x1 = x_normed ? u[2 * i + 1] * nrm : __uint_as_float(wx[i] & 0xffff0000u);
         const int k = head * D + sub * 8 + 2 * i;
         s1 += v[2 * i] * lx.wbar[k] + v[2 * i + 1] * lx.wbar[k + 1];
         s2 += v[2 * i] * x0 + v[2 * i + 1] * x1;
@@ -499,7 +508,7 @@ int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_n
 
 int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
                         float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
-                        int x_hm_n, float* partials, void* stream) {
+                        int x_hm_n, int x_normed, float* partials, void* stream) {
   const long npairs = rows * heads;
   if (npairs <= 0) return 0;
   if ((dhead != 32 && dhead != 64) || !partials || (x_hm_n > 0 && rows % x_hm_n)) return (int)hipErrorInvalidValue;
@@ -509,10 +518,10 @@ int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, co
   dim3 grid((unsigned)blocks), block(256);
   if (lph == 4)
     hipLaunchKernelGGL(headnorm_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
-                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n, HeadLnx{});
+                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n, x_normed, HeadLnx{});
   else
     hipLaunchKernelGGL(headnorm_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x,
-                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n, HeadLnx{});
+                       inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n, x_normed, HeadLnx{});
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return ctclip_reduce_partials(partials, (int)blocks, dhead, dhead, dscale, (hipStream_t)stream);
@@ -521,17 +530,18 @@ int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, co
 int ctclip_headnorm_bwd_ln(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
                            float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
                            const float* rstd, const float* wbar, int ln_dim, void* dx_scaled, long lddxs, float* c1, float* c2,
-                           float* partials, void* stream) {
+                           int x_hm_n, int x_normed, float* partials, void* stream) {
   const long npairs = rows * heads;
   if (npairs <= 0) return 0;
   if (dhead != 32 || heads != 8 || !partials || !rstd || !wbar || !dx_scaled || !c1 || !c2 || ln_dim <= 0 || (lddxs & 7) ||
-      (((uintptr_t)dx_scaled) & 15))
+      (((uintptr_t)dx_scaled) & 15) || (x_hm_n > 0 && rows % x_hm_n))
     return (int)hipErrorInvalidValue;
   long blocks = (npairs + 63) / 64;
   if (blocks > 2048) blocks = 2048;
   HeadLnx lx{rstd, wbar, (bf16_t*)dx_scaled, lddxs, c1, c2, 1.0f / (float)ln_dim};
   hipLaunchKernelGGL((headnorm_bwd_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
-                     (const bf16_t*)x, inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, 0, lx);
+                     (const bf16_t*)x, inv_norm, scale, (bf16_t*)dx, partials, npairs, heads, lddy, ldx, lddx, mult, x_hm_n, x_normed,
+                     lx);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   return ctclip_reduce_partials(partials, (int)blocks, dhead, dhead, dscale, (hipStream_t)stream);

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -56,8 +57,8 @@ class ShadowCache:
         if ent is None or ent[2] != ptrs:
             with torch.no_grad():
                 s_ = make()
-            if ent is not None and ent[1] in PLAN.sets:
-                PLAN.sets.remove(ent[1])
+            if ent is not None:
+                PLAN.unregister(ent[1])
             PLAN.register(s_)
             ent = [None, s_, ptrs]
             self._store[key] = ent
@@ -109,13 +110,30 @@ class ShadowSet:
 
 
 class ShadowPlan:
-    """Every registered ShadowSet of the process.  refresh(set) brings a set's destinations up to date: after an optimiser step
+    """Every LIVE ShadowSet of the process.  refresh(set) brings a set's destinations up to date: after an optimiser step
     (the weight epoch moved) the first caller refills ALL sets with one launch; a set whose own parameters were written in
-    place in between is refilled alone."""
+    place in between is refilled alone.
+
+    The sets are held WEAKLY: a set belongs to its module's ShadowCache and pins that module's f32 parameters and every bf16 /
+    transposed shadow tensor (`keep`), so a strong reference here would keep every model ever built in the process resident on
+    the GPU and refill dead models' shadows after each optimiser step.  When a module (or the whole model) is dropped its sets go
+    with it, leave the plan, and the cached all-sets table is rebuilt."""
 
     def __init__(self):
-        self.sets = []
+        self._refs = []                      # weakref.ref(ShadowSet), in registration order
         self.epoch_done = None
+        self._all = None
+
+    @property
+    def sets(self):
+        return [s_ for s_ in (r() for r in self._refs) if s_ is not None]
+
+    def _dropped(self, ref):
+        self._refs = [r for r in self._refs if r is not ref]
+        self._all = None
+
+    def unregister(self, s_):
+        self._refs = [r for r in self._refs if r() is not None and r() is not s_]
         self._all = None
 
     @staticmethod
@@ -135,32 +153,34 @@ class ShadowPlan:
         hip.shadow_multi(table, starts, n, total)
 
     def register(self, s_):
-        self.sets.append(s_)
+        self._refs.append(weakref.ref(s_, self._dropped))
         self._all = None
 
     def prime(self, epoch=None):
         """Bring EVERY registered set up to date on the current stream if the weight epoch moved (what the first refresh() of a
         step does).  Called before work is forked onto a second stream, so that no module refills another stream's shadows."""
         epoch = _weight_epoch if epoch is None else epoch
-        if self.epoch_done != epoch and len(self.sets) > 1:
-            self.refresh(self.sets[0], epoch)
+        live = self.sets
+        if self.epoch_done != epoch and len(live) > 1:
+            self.refresh(live[0], epoch)
         elif self.epoch_done != epoch:
             self.epoch_done = epoch
 
     def refresh(self, s_, epoch):
         """Fill s_'s destinations now.  The first call after the weight epoch moved fills EVERY registered set with one launch
         (and marks them: `fresh_epoch`); later calls in the same epoch fill the one set."""
-        if self.epoch_done != epoch and len(self.sets) > 1:
+        live = self.sets
+        if self.epoch_done != epoch and len(live) > 1:
             if self._all is None:
                 by_dev = {}
-                for x in self.sets:
+                for x in live:
                     by_dev.setdefault(x.device, []).append(x)
                 self._all = {d: self._device_table(v) for d, v in by_dev.items()}
             for d, tab in self._all.items():
                 with torch.cuda.device(d):
                     self._launch(tab)
             self.epoch_done = epoch
-            for x in self.sets:
+            for x in live:
                 x.fresh_epoch = epoch
             return
         if s_._table is None:
@@ -209,6 +229,23 @@ def join_side_streams():
         st = table.get(cur.device.index)
         if st is not None and st != cur:
             cur.wait_stream(st)
+
+
+class JoinAfterBackwardFn(Function):
+    """Identity on the text tower's output, applied on the text stream.  Its backward is the FIRST node autograd runs on that
+    stream; it queues an engine callback that makes the stream `.backward()` was called on wait for the text stream once the
+    whole backward has been issued -- so every `.grad` the text tower accumulated in place is complete on the caller's stream
+    when `backward()` returns, whatever the caller does next (the reference clips gradient norms between backward() and step(),
+    src/utils/CTClipTrainer.py:199-202).  The explicit joins (trainer, HipAdam, GradSync) stay as belt and braces."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        return dy
 
 
 def pad8(n: int) -> int:
@@ -510,6 +547,9 @@ class PegFn(Function):
 # ---------------------------------------------------------------------------------------------------
 LOG2E = 1.4426950408889634
 LN2 = 0.6931471805599453
+# q / k cosine normalisation inside the projections' GEMM epilogue (ctclip_gemm_bf16_headnorm); CTCLIP_HEADNORM_IN_GEMM=0 keeps
+# the separate head-norm pass over the raw projections (A/B runs, and the path of head sizes other than 32)
+HEADNORM_IN_GEMM = os.environ.get("CTCLIP_HEADNORM_IN_GEMM", "1") != "0"
 
 
 def deterministic() -> bool:
@@ -555,7 +595,7 @@ class AttentionFn(Function):
         n1, _, mean, rstd = layernorm(x2, None if fold else gamma.detach(), None, 1e-5)
         x16 = aux.get("x16")
         xb = x16.reshape(M, dim) if (x16 is not None and x16.numel() == M * dim and x16.is_contiguous()) else cast16(x2)
-        q = gemm(n1, sh["wqg" if fold else "wq"], M, inner, dim)
+        wq16 = sh["wqg" if fold else "wq"]
         qinv = torch.empty(M, heads, dtype=F32, device=dev)
         kinv = torch.empty(M, heads, dtype=F32, device=dev)
         o = torch.empty(M, inner, dtype=BF16, device=dev)
@@ -566,13 +606,26 @@ class AttentionFn(Function):
             bias_dense = _c(bias_t.detach().to(F32))
         elif kind == "table":
             bias_dense = aux["dense"]
+        # head size 32, an even number of heads: the cosine normalisation of q and k (attention.py:146-153) runs in the REGISTER
+        # EPILOGUE of their projections (ctclip_gemm_bf16_headnorm) -- the raw q / k are never written, read back or kept; the
+        # backward works from the normalised rows and 1 / norm
+        fusedhn = HEADNORM_IN_GEMM and dp == 32 and inner % 64 == 0 and dim % 32 == 0
+        q = None
         if hm:
             kv = torch.empty(2, nseq, heads, n, dp, dtype=BF16, device=dev)          # QUIRK attention.py:138: kv from un-normalised x
-            hip.gemm_bf16_headmajor(xb, sh["wkv"], kv, M, 2 * inner, dim, xb.stride(0), sh["wkv"].stride(0), n, heads)
             qh = torch.empty(nseq, heads, n, dp, dtype=BF16, device=dev)
-            kh = torch.empty(nseq, heads, n, dp, dtype=BF16, device=dev)
-            hip.headnorm_fwd(q, sh["q_scale"], qh, qinv, M, heads, dp, inner, 0, qmult, 0, n)
-            hip.headnorm_fwd(kv[0], sh["k_scale"], kh, kinv, M, heads, dp, 0, 0, 1.0, n, n)
+            if fusedhn:
+                hip.gemm_bf16_headnorm(xb, sh["wkv"], kv, kinv, sh["k_scale"], M, 2 * inner, dim, xb.stride(0),
+                                       sh["wkv"].stride(0), 0, n, heads, inner, 1.0)
+                hip.gemm_bf16_headnorm(n1, wq16, qh, qinv, sh["q_scale"], M, inner, dim, n1.stride(0), wq16.stride(0), 0, n,
+                                       heads, inner, qmult)
+                kh = kv[0]
+            else:
+                q = gemm(n1, wq16, M, inner, dim)
+                hip.gemm_bf16_headmajor(xb, sh["wkv"], kv, M, 2 * inner, dim, xb.stride(0), sh["wkv"].stride(0), n, heads)
+                kh = torch.empty(nseq, heads, n, dp, dtype=BF16, device=dev)
+                hip.headnorm_fwd(q, sh["q_scale"], qh, qinv, M, heads, dp, inner, 0, qmult, 0, n)
+                hip.headnorm_fwd(kv[0], sh["k_scale"], kh, kinv, M, heads, dp, 0, 0, 1.0, n, n)
             shift = torch.empty(heads + 1, dtype=F32, device=dev)
             if kind == "table":
                 tb = bias_t.detach()
@@ -582,7 +635,18 @@ class AttentionFn(Function):
             else:
                 hip.attn_shift(sh["q_scale"], sh["k_scale"], dp, qmult, None, 0, 0, 0, heads, shift)
             hip.attn_hm_fwd(qh, kh, kv[1], o, lse, bias_dense, shift, nseq, n, heads, inner)
+        elif fusedhn:
+            kv = torch.empty(M, 2 * inner, dtype=BF16, device=dev)   # [normalised k | v]; QUIRK attention.py:138: from un-normalised x
+            qh = torch.empty(M, inner, dtype=BF16, device=dev)
+            hip.gemm_bf16_headnorm(xb, sh["wkv"], kv, kinv, sh["k_scale"], M, 2 * inner, dim, xb.stride(0), sh["wkv"].stride(0),
+                                   2 * inner, 0, heads, inner, 1.0)
+            hip.gemm_bf16_headnorm(n1, wq16, qh, qinv, sh["q_scale"], M, inner, dim, n1.stride(0), wq16.stride(0), inner, 0, heads,
+                                   inner, qmult)
+            kh = kv[:, :inner]
+            hip.attn_fwd(qh, kh, kv[:, inner:], o, lse, bias_dense, None, nseq, n, heads, dp, inner, 2 * inner, 2 * inner,
+                         inner, LN2)
         else:
+            q = gemm(n1, wq16, M, inner, dim)
             kv = gemm(xb, sh["wkv"], M, 2 * inner, dim)           # QUIRK attention.py:138: kv from un-normalised x
             qh = torch.empty_like(q)
             kh = torch.empty(M, inner, dtype=BF16, device=dev)
@@ -593,13 +657,15 @@ class AttentionFn(Function):
         y = gemm(o, sh["wout"], M, dim, inner, out_dtype=F32, resid=x2 if residual else None)
         if want_probs:
             probs = torch.empty(nseq, heads, n, n, dtype=F32, device=dev)
-            hip.attn_probs(qh, kh, lse, bias_dense, None, probs, nseq, n, heads, dp, inner, inner, LN2)
+            hip.attn_probs(qh, kh, lse, bias_dense, None, probs, nseq, n, heads, dp, inner, kh.stride(0), LN2)
         else:
             probs = x.new_empty(0)
         keep_x = x2.new_empty(0) if fold else x2                  # folded: the f32 input row is not kept for the backward
-        ctx.save_for_backward(keep_x, gamma, mean, rstd, n1, xb, q, kv, qh, kh, qinv, kinv, o, lse,
+        # fused head-norm: the raw q does not exist and kh is a view of kv -- neither is saved on its own
+        ctx.save_for_backward(keep_x, gamma, mean, rstd, n1, xb, q if q is not None else x2.new_empty(0), kv, qh,
+                              kh if not fusedhn else x2.new_empty(0), qinv, kinv, o, lse,
                               bias_dense if bias_dense is not None else x2.new_empty(0))
-        ctx.sh, ctx.cfg, ctx.aux, ctx.shape, ctx.hm = sh, cfg, aux, (nseq, n, dim), hm
+        ctx.sh, ctx.cfg, ctx.aux, ctx.shape, ctx.hm, ctx.fusedhn = sh, cfg, aux, (nseq, n, dim), hm, fusedhn
         ctx.params = (gamma, wq, wkv, q_scale, k_scale, wout)
         ctx.mark_non_differentiable(probs)
         return y.reshape(nseq, n, dim), probs
@@ -608,10 +674,13 @@ class AttentionFn(Function):
     @announces
     def backward(ctx, dy, _dprobs):
         x2, gamma, mean, rstd, n1, xb, q, kv, qh, kh, qinv, kinv, o, lse, bias_dense = ctx.saved_tensors
-        sh, aux, hm = ctx.sh, ctx.aux, ctx.hm
+        sh, aux, hm, fusedhn = ctx.sh, ctx.aux, ctx.hm, ctx.fusedhn
         heads, dh, dp, scale, residual, _ = ctx.cfg
         nseq, n, dim = ctx.shape
         M, inner = nseq * n, heads * dp
+        if fusedhn:                                    # the normalised k is the first half of kv; the raw q / k do not exist
+            kh = kv[0] if hm else kv[:, :inner]
+        ldk = inner if (hm or not fusedhn) else 2 * inner
         dev = dy.device
         kind = aux["kind"]
         qmult = float(scale) * LOG2E
@@ -654,17 +723,20 @@ class AttentionFn(Function):
             do = dgrad(dyb, sh["wout"], M, dim, inner, out_dtype=BF16, wT16=sh.get("woutT"))
             hip.attn_bwd(qh, kh, kv[:, inner:], o, do, lse, delta, dqh, dkh, dkv[:, inner:], bias_dense, None,
                          fast_dense, f_rel, fast_table, f_ts, f_gh, f_gw, nseq, n, heads, dp,
-                         inner, inner, 2 * inner, inner, inner, inner, inner, lkv, LN2)
+                         inner, ldk, 2 * inner, inner, inner, inner, inner, lkv, LN2)
         if ordered:
             dense = dbias_dense if dbias_dense is not None else torch.zeros(heads, n, n, dtype=F32, device=dev)
             if hm:
                 hip.attn_dbias_ordered(qh, kh, kv[1], do, lse, delta, bias_dense, dense, nseq, n, heads, 1, 0, 0, 0, 0, LN2)
             else:
                 hip.attn_dbias_ordered(qh, kh, kv[:, inner:], do, lse, delta, bias_dense, dense, nseq, n, heads, 0,
-                                       inner, inner, 2 * inner, inner, LN2)
+                                       inner, ldk, 2 * inner, inner, LN2)
             if dtable is not None:
                 hip.attn_dbias_table(dense, dtable, heads, gh, gw)
+        # what the head-norm backward reads as "x": the raw projections, or (fusedhn) the normalised rows the forward kept
         k_raw, k_ld, k_hm = (kv[0], 0, n) if hm else (kv, 2 * inner, 0)
+        q_x, q_ld, q_hm = (qh, (0 if hm else inner), (n if hm else 0)) if fusedhn else (q, inner, 0)
+        xn = int(fusedhn)
         p_gamma, p_wq, p_wkv, p_qs, p_ks, p_wout = ctx.params
         dq = torch.empty(M, inner, dtype=BF16, device=dev)
         dbias = None
@@ -685,11 +757,11 @@ class AttentionFn(Function):
             if fused:
                 c1 = torch.empty(M, dtype=F32, device=dev)
                 c2 = torch.empty(M, dtype=F32, device=dev)
-                hip.headnorm_bwd_ln(dqh, q, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, inner, inner, qmult,
-                                    rstd, sh["wbar"], dim, dcat, dcat.stride(0), c1, c2)
+                hip.headnorm_bwd_ln(dqh, q_x, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, q_ld, inner, qmult,
+                                    rstd, sh["wbar"], dim, dcat, dcat.stride(0), c1, c2, q_hm, xn)
             else:
-                hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, inner, inner, qmult, 0)
-            hip.headnorm_bwd(dkh, k_raw, kinv, sh["k_scale"], dkv, gks, M, heads, dp, inner, k_ld, lkv, 1.0, k_hm)
+                hip.headnorm_bwd(dqh, q_x, qinv, sh["q_scale"], dq, gqs, M, heads, dp, inner, q_ld, inner, qmult, q_hm, xn)
+            hip.headnorm_bwd(dkh, k_raw, kinv, sh["k_scale"], dkv, gks, M, heads, dp, inner, k_ld, lkv, 1.0, k_hm, xn)
             # both data gradients leave their (store-bound, K = 256 / 512) GEMMs in bf16; the f32 residual-path gradient
             # dy2 is added inside the LayerNorm backward, so the residual stream itself never passes through bf16
             fold = "wqg" in sh
@@ -725,8 +797,8 @@ class AttentionFn(Function):
         dwout = wgrad(dyb, o, dim, inner, M)
         dqs = torch.zeros(dp, dtype=F32, device=dev)
         dks = torch.zeros(dp, dtype=F32, device=dev)
-        hip.headnorm_bwd(dqh, q, qinv, sh["q_scale"], dq, dqs, M, heads, dp, inner, inner, inner, qmult, 0)
-        hip.headnorm_bwd(dkh, kv, kinv, sh["k_scale"], dkv, dks, M, heads, dp, inner, 2 * inner, 2 * inner, 1.0, 0)
+        hip.headnorm_bwd(dqh, q_x, qinv, sh["q_scale"], dq, dqs, M, heads, dp, inner, q_ld, inner, qmult, q_hm, xn)
+        hip.headnorm_bwd(dkh, kv, kinv, sh["k_scale"], dkv, dks, M, heads, dp, inner, 2 * inner, 2 * inner, 1.0, 0, xn)
         dn1 = dgrad(dq, sh["wq"], M, inner, dim, wT16=sh.get("wqT"))
         dwq = wgrad(dq, n1, inner, dim, M)
         dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, resid=dy2 if residual else None, wT16=sh.get("wkvT"))

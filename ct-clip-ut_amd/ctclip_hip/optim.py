@@ -375,8 +375,10 @@ class GradSync:
     # -- launch / join -------------------------------------------------------------------------------------------
     def _launch(self, b):
         chunk = self._flat(b)
+        # the bucket may hold gradients written on the text stream AND on the main one: the stream that starts the collective waits
+        # for the other first -- once per bucket, whatever the backend (a no-op when no second stream exists, e.g. on CPU)
+        ops.join_side_streams()
         if chunk.is_cuda and dist.get_backend(self.group) == "nccl":
-            ops.join_side_streams()                          # the bucket may hold gradients written on the text stream and on the main one
             b["handle"] = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         else:                                                # gloo: no AVG
             b["handle"] = (dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk)

@@ -81,6 +81,8 @@ class CTCLIP(nn.Module):
                 text_output = self.encode_text(text_inputs)
                 text_latents = ops.LinearF32Fn.apply(text_output.to(F32), self.to_text_latent.weight, None, False)  # :115
                 text_latents = ops.RowNormFn.apply(text_latents)                                  # :119
+                if text_latents.requires_grad:
+                    text_latents = ops.JoinAfterBackwardFn.apply(text_latents)   # backward() ends with the caller's stream joined
         else:
             text_output = self.encode_text(text_inputs) if text_inputs else text_embeds      # ctclip.py:107
         image_tokens = self.visual_transformer(image_inputs)                                  # :110

@@ -12,7 +12,7 @@
  *     dynamic-LDS limit once (hipFuncSetAttribute), and the CU count is read once.
  *   - environment: the library reads exactly two variables, both test hooks -- CTCLIP_GEMM_V2_ALL (lower
  *     the size gates of the pipelined GEMM kernels so that small test shapes reach every kernel) and
- *     CTCLIP_ATTN_SP_CHUNK (sequences per workgroup of the sequence-persistent attention kernels, for
+ *     CTCLIP_ATTN_SP_CHUNK (sequences per workgroup of the wave-per-sequence attention kernels, for
  *     ragged-chunk tests).  Results do not depend on either.  Development A/B switches exist only in
  *     builds compiled with -DCTCLIP_TUNING_KNOBS.
  *   - all pointers are DEVICE pointers owned by the caller; "bf16" buffers are raw uint16 storage.
@@ -62,6 +62,16 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
                      int M, int N, int K, long lda, long ldb, long ldc, long ldr,
                      int a_kmajor, int b_kmajor, int c_fp32, int split_k, int accumulate, float alpha, int act,
                      float* splitk_ws, long splitk_ws_floats, void* stream);
+
+/* The same k-major x k-major product on the one-wave-per-SIMD kernel (csrc/gemm5.hip: 4 waves x 128 x 128, accumulators in
+ * AccVGPRs, paired full-line LDS-DMA) CALLED DIRECTLY: ctclip_gemm_bf16 / _geglu / _geglu_bwd send it the shapes it measured
+ * faster on (FF1 + GEGLU, N >= 2048); this entry takes any shape the kernel is eligible for -- K % 64 == 0, K >= 192, 16-byte
+ * aligned outputs -- and returns hipErrorInvalidValue otherwise (so short rings, K = 192 .. 960, can be tested and measured
+ * without a size gate).  act: 0 none, 1 erf-GELU, 2 = FF1 + GEGLU (C = h [M, N] in [value 32 | gate 32] blocks, G = g
+ * [M, N / 2]), 3 = FF2 data gradient + GEGLU backward (G = h, overwritten by d(h); C unused).  Reference: every nn.Linear of
+ * src/utils/attention.py:38-51,118-124. */
+int ctclip_gemm5_bf16(const void* A, const void* B, void* C, const float* bias, const float* resid, int M, int N, int K, long lda,
+                      long ldb, long ldc, long ldr, int c_fp32, float alpha, int act, void* G, long ldg, void* stream);
 
 /* scores = A[M,K] B[N,K]^T without materialising them: per column n, the top-2 (value, row) of each 64-row
  * slab of M.  part_val/part_idx are [N][2*ceil(M/128)][2]; empty slots carry index 0x7fffffff.  VQ nearest-code
@@ -126,17 +136,31 @@ int ctclip_gemm_bf16_lnbwd(const void* A, const void* B, float* dx, void* dx_bf1
  * sequence (rows % x_hm_n == 0; its ld is ignored) -- the operand layout of ctclip_attn_hm_*; 0: row-major [rows, ld]. */
 int ctclip_headnorm_fwd(const void* x, const float* scale, void* y, float* inv_norm, long rows, int heads, int dhead,
                         long ldx, long ldy, float mult, int x_hm_n, int y_hm_n, void* stream);
+/* backward.  x_normed = 0: `x` is the raw projection the forward read.  x_normed = 1: `x` is the forward's OUTPUT y = u scale mult
+ * (the projection normalised in its GEMM epilogue by ctclip_gemm_bf16_headnorm, nothing else of it kept): u = y / (scale mult),
+ * raw row = u / inv_norm; a channel whose learned scale is exactly 0 gets no gradient through it. */
 int ctclip_headnorm_bwd(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
                         float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
-                        int x_hm_n, float* partials, void* stream);
+                        int x_hm_n, int x_normed, float* partials, void* stream);
 /* the same for the q path of a block whose LayerNorm backward runs inside ctclip_gemm_bf16_lnbwd: also writes
  * dx_scaled[row][:] = rstd[row] dx[row][:] (bf16, row stride lddxs) and the two row constants of that epilogue,
  * c1[row] = rstd/ln_dim sum_k dx_k wbar_k and c2[row] = rstd/ln_dim sum_k dx_k x_k (dx as rounded to bf16).
- * heads * dhead == 256 and dhead == 32 (a row's heads are the 32 lanes of half a wave), x row-major. */
+ * heads * dhead == 256 and dhead == 32 (a row's heads are the 32 lanes of half a wave); x_hm_n / x_normed as above. */
 int ctclip_headnorm_bwd_ln(const void* dy, const void* x, const float* inv_norm, const float* scale, void* dx,
                            float* dscale, long rows, int heads, int dhead, long lddy, long ldx, long lddx, float mult,
                            const float* rstd, const float* wbar, int ln_dim, void* dx_scaled, long lddxs, float* c1, float* c2,
-                           float* partials, void* stream);
+                           int x_hm_n, int x_normed, float* partials, void* stream);
+
+/* The q / k (or k | v) projection WITH the per-head cosine normalisation in the GEMM's register epilogue (attention.py:142,
+ * 146-153): C = A[M,K] B[N,K]^T, and every head (32 columns) of the first norm_cols columns leaves as
+ *   y = x / max(|x|, 1e-12) * scale[d] * mult        inv_norm[row][head] = 1 / max(|x|, 1e-12)   ([M, norm_cols / 32] f32)
+ * computed from the f32 accumulators (a head's 32 columns sit in four lanes of the wave: two lane-row swaps); columns behind
+ * norm_cols are stored as they are (the v half of a kv product).  The raw projection is never written: the backward works from y
+ * (ctclip_headnorm_bwd with x_normed = 1).  n_tokens > 0: C in the head-major layout [part][sequence][head][token][32] of
+ * ctclip_gemm_bf16_headmajor (ldc ignored); n_tokens = 0: row-major [M, ldc].  dhead is 32; K % 32 == 0, N % 64 == 0,
+ * norm_cols % 64 == 0, C 16-byte aligned.  Replaces the head-norm pass over q and over k and the round trip of the raw q / k. */
+int ctclip_gemm_bf16_headnorm(const void* A, const void* B, void* C, float* inv_norm, const float* scale, int M, int N, int K,
+                              long lda, long ldb, long ldc, int n_tokens, int heads, int norm_cols, float mult, void* stream);
 
 /* ---- fused attention (attention.py:155-180; BertSelfAttention) ----------------------------------
  * q,k,v,o: [nseq*n, ld] bf16, head h in columns h*dhead.. ; dhead in {32,64}.

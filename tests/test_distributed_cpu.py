@@ -299,8 +299,9 @@ def test_bench_self_launches_its_ranks_from_a_plain_shell():
     """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment (how the driver starts the scaling run): the
     parent starts two ranks through torch.distributed.run on 127.0.0.1, both rendezvous (gloo here) before anything touches a
     device, and the parent returns the children's exit code -- non-zero in this GPU-less container, where the training step
-    refuses to run ("no HIP device visible": there is no CPU fallback).  On a GPU box the same command prints the JSON line
-    (profiles/r04_self_launch_two_ranks.json)."""
+    refuses to run ("no HIP device visible": there is no CPU fallback).  On a GPU box the same command prints the JSON line:
+    tests/test_hip_trainer.py::test_bench_two_gloo_ranks_share_the_gpu asserts its n_gpus / global_batch / negatives there.
+    The parent counts devices from sysfs (bench.visible_gpus), never through the HIP runtime."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["CTCLIP_DIST_BACKEND"] = "gloo"
@@ -317,6 +318,83 @@ def test_bench_self_launches_its_ranks_from_a_plain_shell():
         import json
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert r.returncode == 0 and line["n_gpus"] == 2
+
+
+def test_self_launch_parent_never_touches_the_device_runtime(monkeypatch):
+    """bench.self_launch (the parent of `python bench.py --gpus N`) must start its ranks from a process that has not initialised
+    HIP: it counts devices from sysfs (bench.visible_gpus) and never calls torch.cuda.*; the visibility variables cut the
+    count.  Checked by making every torch.cuda entry point it could reach raise."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    import subprocess
+
+    def boom(*a, **k):
+        raise AssertionError("self_launch touched torch.cuda")
+    for name in ("device_count", "is_available", "init", "current_device", "set_device"):
+        monkeypatch.setattr(torch.cuda, name, boom)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 0
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 2)                  # fewer devices than ranks: refused, nothing started
+    seen.clear()
+    assert bench.self_launch(4) == 2 and not seen
+    monkeypatch.undo()
+    # the sysfs reader itself: the visibility variables cut the count, a box without KFD says None
+    import glob as _glob
+    nodes = _glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    n = bench.visible_gpus()
+    assert (n is None) == (not nodes)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _join_called_once_per_bucket(rank):
+    """GradSync._launch: the stream that starts a bucket's collective first waits for the other one (ops.join_side_streams --
+    the text tower's gradients are written on a second HIP stream).  On CPU there are no streams and the call is a no-op, but
+    it must be MADE exactly once per bucket launch, hook-driven launches and the tail of all_reduce_grads() alike, so that the
+    first multi-GPU run cannot reduce a bucket that still has text-tower kernels in flight."""
+    from ctclip_hip import ops
+    from ctclip_hip.optim import GradSync
+    calls = []
+    real = ops.join_side_streams
+
+    def counted():
+        calls.append(1)
+        return real()
+    ops.join_side_streams = counted
+    try:
+        torch.manual_seed(rank)
+        grads = [torch.randn(1000), torch.randn(37)]
+        sync = GradSync(_FakeArenaOpt(grads), bucket_mb=1)
+        sync.bucket_elems = 256                                                # several buckets + a ragged tail
+        sync.all_reduce_grads()
+        nb = len(sync._buckets)
+        assert nb >= 2 and len(calls) == nb, (nb, len(calls))
+        calls.clear()
+        sync.all_reduce_grads()                                                # second step: once per bucket again
+        assert len(calls) == nb
+    finally:
+        ops.join_side_streams = real
+
+
+def test_gradsync_joins_the_text_stream_once_per_bucket():
+    _run(_join_called_once_per_bucket)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

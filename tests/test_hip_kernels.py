@@ -156,7 +156,7 @@ def test_linear_geglu_fused_and_blocked_backward(hip, M, inner, K):
                                    (1000, 264, 2816),      # ragged in both directions, N % 256 != 0 (FF1 data-gradient K)
                                    (3072, 768, 1024)])     # all tiles interior
 def test_gemm_one_wave_per_simd_tile(hip, M, N, K):
-    """k-major x k-major products with K % 64 == 0 and K >= 1024 go to csrc/gemm5.hip (4 waves x 128 x 128, accumulators in
+    """k-major x k-major products with K % 64 == 0 and K >= 1024 go to csrc/gemm5.hip under the suite's size gates (4 waves x 128 x 128, accumulators in
     AccVGPRs, flattened (tile, K-step) ring): every epilogue form of gemm_tile.h against f32 torch math on the same bf16
     operands -- f32 + bias + residual + alpha, bf16 + bias + erf-GELU, head-major bf16, FF1 + GEGLU, FF2 dgrad + GEGLU
     backward (reference attention.py:38-51,118-124)."""
@@ -202,6 +202,51 @@ def test_gemm_one_wave_per_simd_tile(hip, M, N, K):
         got = h2.float().view(M, inner // 32, 2, 32)
         check("gemm5 dgrad + geglu dval", got[:, :, 0].reshape(M, inner), val.grad, 2.5e-2)
         check("gemm5 dgrad + geglu dgate", got[:, :, 1].reshape(M, inner), gate.grad, 2.5e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(70000, 256, 192),      # nk = 6: the ring fill nearly spans a tile; 274 tiles > CUs: the flattened ring crosses
+                                   #                         tiles every six steps, ragged last row tile (C_ST / `post` wait path)
+                                   (66000, 512, 320),      # nk = 10, 516 tiles
+                                   (3000, 2816, 512),      # production FF1 + GEGLU: K = 512, N = 2 x 1408
+                                   (2048, 3072, 768),      # BERT intermediate: K = 768, N = 3072
+                                   (1000, 264, 960)])      # ragged both ways, N % 256 != 0, the longest "short" ring
+def test_gemm_one_wave_per_simd_short_rings(hip, M, N, K):
+    """csrc/gemm5.hip through its direct entry (ctclip_gemm5_bf16) on the K = 192 .. 960 rings the dispatcher's size gates keep
+    away from it in the suite but a training run sends there (FF1 + GEGLU at K = 512, BERT's K = 768 / N = 3072; reference
+    attention.py:38-51, BertIntermediate): every epilogue form against f32 torch math on the same bf16 operands, several
+    tiles per workgroup, ragged edges."""
+    A, B = bf(rnd(M, K, seed=21) * 0.5), bf(rnd(N, K, seed=22) * 0.5)
+    ref = A.float() @ B.float().t()
+    bias, res = rnd(N, seed=5), rnd(M, N, seed=6)
+    C = torch.empty(M, N, device=DEV)
+    hip.gemm5_bf16(A, B, C, bias, res, M, N, K, K, K, N, N, 1, 0.5, 0, None, 0)
+    check(f"gemm5 direct f32 + bias + resid {M}x{N}x{K}", C, 0.5 * ref + bias + res, 2e-3)
+    del C, res
+    C16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.gemm5_bf16(A, B, C16, bias, None, M, N, K, K, K, N, 0, 0, 1.0, 1, None, 0)
+    check("gemm5 direct bf16 + bias + gelu", C16, torch.nn.functional.gelu(ref + bias), 1e-2)
+    if N % 128 == 0:
+        inner = N // 2
+        Hh = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        G = torch.empty(M, inner, device=DEV, dtype=torch.bfloat16)
+        hip.gemm5_bf16(A, B, Hh, None, None, M, N, K, K, K, N, 0, 0, 1.0, 2, G, inner)
+        hb = ref.view(M, inner // 32, 2, 32)
+        check("gemm5 direct fused h", Hh, ref, 1e-2)
+        check("gemm5 direct fused g", G, (torch.nn.functional.gelu(hb[:, :, 1]) * hb[:, :, 0]).reshape(M, inner), 1.5e-2)
+        h0 = bf(rnd(M, 2 * inner, seed=13))
+        h2 = h0.clone()
+        hip.gemm5_bf16(A, B[:inner], None, None, None, M, inner, K, K, K, 0, 0, 0, 1.0, 3, h2, 2 * inner)
+        dg = bf(A.float() @ B[:inner].float().t()).float()
+        hv = h0.float().view(M, inner // 32, 2, 32)
+        val = hv[:, :, 0].reshape(M, inner).clone().requires_grad_(True)
+        gate = hv[:, :, 1].reshape(M, inner).clone().requires_grad_(True)
+        (torch.nn.functional.gelu(gate) * val).backward(dg)
+        got = h2.float().view(M, inner // 32, 2, 32)
+        check("gemm5 direct dgrad + geglu dval", got[:, :, 0].reshape(M, inner), val.grad, 2.5e-2)
+        check("gemm5 direct dgrad + geglu dgate", got[:, :, 1].reshape(M, inner), gate.grad, 2.5e-2)
+    # not eligible: K not a whole number of k64 pairs / shorter than the ring fill -> refused before anything is launched
+    with pytest.raises(RuntimeError):
+        hip.gemm5_bf16(A, B, C16, None, None, M, N, 160, K, K, N, 0, 0, 1.0, 0, None, 0)
 
 
 def test_gemm_mfma_orientation_asymmetric(hip):
@@ -362,7 +407,7 @@ def test_vq_topk_code_groups(hip, C_, T, K, groups):
     (3, 128, 4, 64, False, True),      # BERT shape with a padding mask
     (2, 40, 2, 32, True, False),       # ragged rows, dense bias and its gradient
     (2, 6, 3, 64, False, True),        # n % 4 != 0: byte-wise flag reads
-    (2, 64, 2, 32, False, False),      # would take the sequence-persistent kernels without dropout
+    (2, 64, 2, 32, False, False),      # would take the wave-per-sequence kernels (attention_ws.hip) without dropout
     (4, 24, 2, 32, False, False),      # would take the one-wave backward without dropout
 ])
 def test_attention_probability_dropout(hip, nseq, n, H, D, use_bias, use_mask):
@@ -494,7 +539,7 @@ def test_headnorm_fwd_bwd(hip, D):
     ref.backward(dy.float().reshape(rows, H, D))
     dx = torch.empty(rows, H * D, device=DEV, dtype=torch.bfloat16)
     ds = torch.zeros(D, device=DEV)
-    hip.headnorm_bwd(dy, x, inv, sc, dx, ds, rows, H, D, H * D, x.stride(0), H * D, mult, 0)
+    hip.headnorm_bwd(dy, x, inv, sc, dx, ds, rows, H, D, H * D, x.stride(0), H * D, mult, 0, 0)
     check("headnorm dx", dx.float().reshape(rows, H, D), xr.grad, 1e-2)
     check("headnorm dscale", ds, scr.grad, 1e-3)
 
@@ -518,8 +563,8 @@ def attn_ref(q, k, v, bias, mask, scale):
     (2, 40, 2, 32, True, False),       # ragged: n not a multiple of 32
     (2, 6, 4, 32, True, True),         # n % 4 != 0
     (1, 512, 2, 64, False, True),      # BERT L=512 (128 KiB of LDS)
-    (7, 320, 3, 32, True, False),      # sequence-persistent kernels, 10 tiles over 8 waves (2 + 1 per wave)
-    (5, 256, 2, 32, False, False),     # sequence-persistent kernels without a bias
+    (7, 320, 3, 32, True, False),      # wave-per-sequence kernels (attention_ws.hip), 10 key tiles, odd head count
+    (5, 256, 2, 32, False, False),     # wave-per-sequence kernels without a bias
     (4, 160, 2, 32, True, False),      # 5 tiles: the last query-block / key-block pair of a workgroup is half empty
     (2, 640, 1, 32, True, False),      # 20 tiles: the fused dQ + d(bias) pass only has room for 8 waves here
     (2, 704, 1, 32, True, False),      # 22 tiles: forward by the wave-per-sequence kernel, backward by the per-sequence kernels (LDS)
@@ -658,9 +703,9 @@ def test_headnorm_and_gemm_write_head_major(hip):
     assert torch.equal(y2, y_hm)
     dy = bf(rnd(rows, H * D, seed=92))
     dx_rm, ds_rm = torch.empty_like(x), torch.zeros(D, device=DEV)
-    hip.headnorm_bwd(dy, x, inv_rm, sc, dx_rm, ds_rm, rows, H, D, H * D, H * D, H * D, 8.0, 0)
+    hip.headnorm_bwd(dy, x, inv_rm, sc, dx_rm, ds_rm, rows, H, D, H * D, H * D, H * D, 8.0, 0, 0)
     dx2, ds2 = torch.empty_like(x), torch.zeros(D, device=DEV)
-    hip.headnorm_bwd(dy, x_hm, inv_rm, sc, dx2, ds2, rows, H, D, H * D, 0, H * D, 8.0, n)   # x head-major
+    hip.headnorm_bwd(dy, x_hm, inv_rm, sc, dx2, ds2, rows, H, D, H * D, 0, H * D, 8.0, n, 0)   # x head-major
     assert torch.equal(dx2, dx_rm) and torch.equal(ds2, ds_rm)
     # GEMM: M = 288 rows (one full 256-row tile + a ragged one), N = 2 parts x 4 heads x 32
     A, B = bf(rnd(rows, K, seed=93)), bf(rnd(2 * H * D, K, seed=94))
@@ -671,6 +716,66 @@ def test_headnorm_and_gemm_write_head_major(hip):
     want = torch.stack((to_hm(C_rm[:, : H * D], nseq, n, H, D), to_hm(C_rm[:, H * D:], nseq, n, H, D)))
     check("head-major GEMM output", C_hm, want.float(), 1e-2)
     assert torch.equal(C_hm, want)                                            # same kernel, same arithmetic: only the addresses differ
+
+
+@pytest.mark.parametrize("nseq,n,H,K", [(3, 96, 4, 64),       # 288 rows: one full 256-row tile + a ragged one; N = 256 (k | v: 2 x 4 heads)
+                                        (28, 576, 8, 512),     # the CT-ViT spatial block: 16 128 rows, dim 512, 8 heads
+                                        (700, 24, 8, 512),     # the temporal block's rows (row-major output is what it uses)
+                                        (5, 40, 2, 96)])       # one slab per part, three K-steps
+def test_projection_with_head_norm_in_the_gemm_epilogue(hip, nseq, n, H, K):
+    """ctclip_gemm_bf16_headnorm: the q projection and the k | v projection with the per-head cosine normalisation of
+    attention.py:146-153 in the GEMM's register epilogue (gemm_tile.h EPI 5) -- head-major and row-major outputs, 1 / norm, the v
+    half untouched -- against f32 torch on the same bf16 operands; then ctclip_headnorm_bwd from the NORMALISED rows (x_normed = 1:
+    the raw projection is never kept) against autograd through F.normalize * scale."""
+    D = 32
+    M, inner = nseq * n, H * D
+    A = bf(rnd(M, K, seed=301))
+    Wq, Wkv = bf(rnd(inner, K, seed=302) * 0.2), bf(rnd(2 * inner, K, seed=303) * 0.2)
+    qs, ks = 1 + 0.2 * rnd(D, seed=304), 1 + 0.2 * rnd(D, seed=305)
+    mult = 8.0 * 1.4426950408889634
+    q_raw, kv_raw = A.float() @ Wq.float().t(), A.float() @ Wkv.float().t()
+    unit = lambda t: torch.nn.functional.normalize(t.reshape(M, H, D), dim=-1)
+    q_ref = (unit(q_raw) * qs * mult).reshape(M, inner)
+    k_ref = (unit(kv_raw[:, :inner]) * ks).reshape(M, inner)
+    qinv_ref = 1.0 / q_raw.reshape(M, H, D).norm(dim=-1).clamp_min(1e-12)
+    kinv_ref = 1.0 / kv_raw[:, :inner].reshape(M, H, D).norm(dim=-1).clamp_min(1e-12)
+    # head-major
+    qh = torch.full((nseq, H, n, D), 7.0, device=DEV, dtype=torch.bfloat16)
+    kvh = torch.full((2, nseq, H, n, D), 7.0, device=DEV, dtype=torch.bfloat16)
+    qinv, kinv = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV)
+    hip.gemm_bf16_headnorm(A, Wq, qh, qinv, qs, M, inner, K, K, K, 0, n, H, inner, mult)
+    hip.gemm_bf16_headnorm(A, Wkv, kvh, kinv, ks, M, 2 * inner, K, K, K, 0, n, H, inner, 1.0)
+    check("q normalised, head-major", qh, to_hm(q_ref, nseq, n, H, D), 1e-2)
+    check("k normalised, head-major", kvh[0], to_hm(k_ref, nseq, n, H, D), 1e-2)
+    check("v untouched, head-major", kvh[1], to_hm(kv_raw[:, inner:], nseq, n, H, D), 1e-2)
+    check("1 / |q|", qinv, qinv_ref, 2e-3)
+    check("1 / |k|", kinv, kinv_ref, 2e-3)
+    # row-major (ldc > N for q: the columns beyond stay untouched)
+    q_rm = torch.zeros(M, inner + 64, device=DEV, dtype=torch.bfloat16)
+    kv_rm = torch.empty(M, 2 * inner, device=DEV, dtype=torch.bfloat16)
+    qinv2, kinv2 = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV)
+    hip.gemm_bf16_headnorm(A, Wq, q_rm, qinv2, qs, M, inner, K, K, K, inner + 64, 0, H, inner, mult)
+    hip.gemm_bf16_headnorm(A, Wkv, kv_rm, kinv2, ks, M, 2 * inner, K, K, K, 2 * inner, 0, H, inner, 1.0)
+    assert torch.equal(to_hm(q_rm[:, :inner], nseq, n, H, D), qh) and torch.equal(qinv2, qinv)     # same arithmetic, other addresses
+    assert float(q_rm[:, inner:].float().abs().max()) == 0.0
+    assert torch.equal(to_hm(kv_rm[:, :inner], nseq, n, H, D), kvh[0]) and torch.equal(to_hm(kv_rm[:, inner:], nseq, n, H, D), kvh[1])
+    assert torch.equal(kinv2, kinv)
+    # backward from the normalised rows: against autograd through normalize * scale * mult at the raw projection
+    dy = bf(rnd(M, inner, seed=306))
+    qr = q_raw.reshape(M, H, D).clone().requires_grad_(True)
+    qsr = qs.clone().requires_grad_(True)
+    (torch.nn.functional.normalize(qr, dim=-1) * qsr * mult).backward(dy.float().reshape(M, H, D))
+    for x_in, ldx, hmn in ((q_rm, inner + 64, 0), (qh, 0, n)):
+        dx, ds = torch.empty(M, inner, device=DEV, dtype=torch.bfloat16), torch.zeros(D, device=DEV)
+        hip.headnorm_bwd(dy, x_in, qinv, qs, dx, ds, M, H, D, inner, ldx, inner, mult, hmn, 1)
+        check(f"dq from the normalised rows (hm_n {hmn})", dx, qr.grad.reshape(M, inner), 1.2e-2)
+        check("d(q_scale) from the normalised rows", ds, qsr.grad, 5e-3)
+    # a zero row (|x| = 0): 1 / norm saturates at 1e12, the output row is 0, nothing is NaN
+    A0 = A.clone()
+    A0[1] = 0
+    hip.gemm_bf16_headnorm(A0, Wq, qh, qinv, qs, M, inner, K, K, K, 0, n, H, inner, mult)
+    assert float(qh.float().abs().reshape(nseq, H, n, D)[0, :, 1].max()) == 0.0 and bool(torch.isfinite(qinv).all())
+    assert float(qinv[1].min()) > 9e11
 
 
 @pytest.mark.parametrize("nseq,n,H,use_bias,chunk", [
@@ -1020,7 +1125,7 @@ def test_two_stage_reductions_are_bitwise_reproducible(hip):
         qn, inv = torch.empty_like(q), torch.empty(rows, H, device=DEV)
         hip.headnorm_fwd(q, sc, qn, inv, rows, H, D, H * D, H * D, 8.0, 0, 0)
         dxh, ds = torch.empty_like(q), torch.zeros(D, device=DEV)
-        hip.headnorm_bwd(dq, q, inv, sc, dxh, ds, rows, H, D, H * D, H * D, H * D, 8.0, 0)
+        hip.headnorm_bwd(dq, q, inv, sc, dxh, ds, rows, H, D, H * D, H * D, H * D, 8.0, 0, 0)
         out["headnorm dscale"] = ds
         cs = torch.zeros(dim, device=DEV)
         hip.colsum_accum(dy, 0, rows, dim, dim, cs)
@@ -1145,8 +1250,22 @@ def test_attention_input_gradient_with_layernorm_backward_in_the_gemm(hip):
     c1, c2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
     wbar = wqg.float().sum(1).contiguous()
     hip.headnorm_bwd_ln(dqh, q16, qinv.contiguous(), qs, dq, gqs, M, H, D, inner, inner, inner, mult, rstd, wbar, dim, dcat,
-                        3 * inner, c1, c2)
+                        3 * inner, c1, c2, 0, 0)
     check("dq (head-norm backward)", dq, dq_ref, 1e-2)
+    # the same from the NORMALISED rows (x_normed = 1: what the block keeps when the q projection normalises in its epilogue),
+    # row-major and head-major: dq, the scaled copy and both row constants must agree with the raw-row form
+    nseq_, n_ = 10, 100
+    qn16 = bf(torch.nn.functional.normalize(q16.float().view(M, H, D), dim=-1) * qs * mult).reshape(M, inner)
+    for x_in, ldx, hmn in ((qn16, inner, 0), (to_hm(qn16, nseq_, n_, H, D), 0, n_)):
+        dq_n, gqs_n = torch.empty_like(dq), torch.zeros(D, device=DEV)
+        dcat_n, c1n, c2n = torch.empty_like(dcat), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        hip.headnorm_bwd_ln(dqh, x_in, qinv.contiguous(), qs, dq_n, gqs_n, M, H, D, inner, ldx, inner, mult, rstd, wbar, dim, dcat_n,
+                            3 * inner, c1n, c2n, hmn, 1)
+        check(f"dq from normalised rows (hm_n {hmn})", dq_n, dq_ref, 1e-2)
+        check("d(q_scale) from normalised rows", gqs_n, gqs, 5e-3)
+        check("rstd-scaled dq from normalised rows", dcat_n[:, :inner], rstd[:, None] * dq_n.float(), 1e-2)
+        check("c1 from normalised rows", c1n, c1, 2e-2)
+        assert float((c2n - c2).abs().max()) <= 2e-2 * float(c1.abs().max())       # c2 = rounding noise around 0 (dq is orthogonal to q)
     check("rstd-scaled dq", dcat[:, :inner], rstd[:, None] * dq.float(), 1e-2)
     wcat = torch.cat((wqg.t(), bf(wkv).t()), 1).contiguous()                  # [dim, 3 inner]
     dx, dx16 = torch.empty(M, dim, device=DEV), torch.empty(M, dim, device=DEV, dtype=torch.bfloat16)

@@ -547,3 +547,76 @@ def test_config1_two_training_steps():
               f"grad-norm {trainer.optim.grad_norm():.4f} / {ref_norms[s]:.4f}")
         assert math.isfinite(loss) and rel <= 5e-2      # free-running codes on a 64-token toy: see test_config1_vs_oracle
         assert abs(trainer.optim.grad_norm() - ref_norms[s]) <= 0.1 * ref_norms[s]       # free-running codes
+
+
+def test_dropped_model_leaves_the_shadow_plan_and_frees_its_memory():
+    """ops.PLAN refills every module's weight shadows with one launch per optimiser step; it must hold the sets weakly, or every
+    model built in the process stays resident on the GPU and is refilled forever (two trainers in one process, sweeps, eval
+    copies).  Build two models, run both once, drop one: its sets leave the plan, its memory is returned, the survivor's forward
+    is unchanged."""
+    import gc
+    from ctclip_hip import ops
+    gc.collect()
+    torch.cuda.synchronize()
+    base_sets, base_mem = len(ops.PLAN.sets), torch.cuda.memory_allocated()
+    clip_a, data, _ = _config1()
+    clip_b, _, _ = _config1()
+    clip_a, clip_b = clip_a.to(DEV).eval(), clip_b.to(DEV).eval()
+    txt, vol = data[0]
+    txt = {k: v.to(DEV) for k, v in txt.items()}
+    with torch.no_grad():
+        sim_a = clip_a(txt, vol.to(DEV))[0].clone()
+        clip_b(txt, vol.to(DEV))
+    both_sets, both_mem = len(ops.PLAN.sets), torch.cuda.memory_allocated()
+    per_model = (both_sets - base_sets) // 2
+    assert per_model >= 4 and both_sets - base_sets == 2 * per_model
+    del clip_b
+    gc.collect()
+    torch.cuda.synchronize()
+    assert len(ops.PLAN.sets) == base_sets + per_model
+    freed = both_mem - torch.cuda.memory_allocated()
+    assert freed > 0.4 * (both_mem - base_mem - sim_a.numel() * 4), (freed, both_mem - base_mem)
+    ops.bump_weight_epoch()                                              # as after an optimiser step: ONE launch over the live sets only
+    with torch.no_grad():
+        sim_again = clip_a(txt, vol.to(DEV))[0]
+    assert torch.equal(sim_a, sim_again)
+    del clip_a
+    gc.collect()
+    assert len(ops.PLAN.sets) == base_sets
+
+
+def test_backward_joins_the_text_stream_by_itself():
+    """The text tower runs (forward and backward) on its own HIP stream and accumulates its gradients in place; `.backward()`
+    must leave them complete on the CALLER's stream without anyone calling ops.join_side_streams() -- a custom loop that clips
+    or logs gradient norms between backward() and step() is the reference's own pattern (src/utils/CTClipTrainer.py:199-202).
+    ops.JoinAfterBackwardFn queues the join as an autograd-engine callback: it is made exactly once per backward, and a norm
+    read right after backward() equals the norm read after a device-wide synchronise."""
+    from ctclip_hip import ops
+    from ctclip_hip.optim import HipAdam
+    if not ops._text_stream["on"]:
+        pytest.skip("CTCLIP_TEXT_STREAM=0")
+    clip, data, _ = _config1()
+    clip = clip.to(DEV).train()
+    opt = HipAdam([p for p in clip.parameters()], lr=1e-4)
+    opt.zero_grad()
+    txt, vol = data[0]
+    sim = clip({k: v.to(DEV) for k, v in txt.items()}, vol.to(DEV))[0]
+    loss = ops.InfoNCEFn.apply(sim)
+    calls = []
+    real = ops.join_side_streams
+
+    def counted():
+        calls.append(torch.cuda.current_stream().cuda_stream)
+        return real()
+    ops.join_side_streams = counted
+    try:
+        main = torch.cuda.current_stream().cuda_stream
+        loss.backward()
+    finally:
+        ops.join_side_streams = real
+    assert calls == [main], calls                       # once, and with the caller's stream current
+    text = [p for n, p in clip.named_parameters() if n.startswith("text_transformer.") and p.grad is not None]
+    norm_now = torch.stack([p.grad.float().square().sum() for p in text]).sum().sqrt()
+    torch.cuda.synchronize()
+    norm_later = torch.stack([p.grad.float().square().sum() for p in text]).sum().sqrt()
+    assert float(norm_now) == float(norm_later) and float(norm_now) > 0

@@ -153,3 +153,27 @@ def test_production_geometry_loss_gradients_and_code_flips():
     for k, p in named.items():
         if k not in grads_o and p.numel():
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+
+
+@pytest.mark.skipif(bool(os.environ.get("CTCLIP_TEST_PRODUCT_GATES")), reason="this IS the product-gates child run")
+def test_parity_suites_with_the_training_runs_gemm_gates():
+    """The suite's default hook (CTCLIP_GEMM_V2_ALL, tests/conftest.py) widens the GEMM size gates, so in this process the
+    production-geometry model sends FF1 + GEGLU (K = 512) and BERT's K = 768 / N = 3072 products partly to other kernels than a
+    training run does.  The library reads the hook once per process, so the model / production parity tests are run once more
+    in a fresh child process with the gates a training run has (CTCLIP_TEST_PRODUCT_GATES=1: gemm5 takes act == GEGLU and
+    N >= 2048, gemm3 the rest; reference src/utils/attention.py:38-51).  One child at a time, started after this process's own
+    GPU work is idle."""
+    import subprocess
+    import sys
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CTCLIP_TEST_PRODUCT_GATES="1")
+    env.pop("CTCLIP_GEMM_V2_ALL", None)
+    cmd = [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_production.py"),
+           os.path.join(root, "tests", "test_hip_model.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    tail = "\n".join((r.stdout or "").splitlines()[-15:])
+    print(tail)
+    assert r.returncode == 0, f"product-gates child run failed:\n{tail}\n{(r.stderr or '')[-2000:]}"
+    assert " passed" in tail and "failed" not in tail

@@ -119,3 +119,31 @@ def test_rccl_branches_run_at_world_size_one():
         sync.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("local", [False, True])
+def test_bench_two_gloo_ranks_share_the_gpu(local):
+    """`python bench.py --gpus 2` from a plain shell (how the driver starts the scaling run), rehearsed on ONE device: the parent
+    counts devices from sysfs and starts two ranks, which rendezvous over gloo (CTCLIP_DIST_BACKEND) and both train on cuda:0 --
+    hook-driven gradient buckets, the fused latent all-gather (BASELINE configs[3]) or `--local-negatives` (configs[2]), the
+    max-over-ranks timing -- and rank 0 prints the ONE JSON line: n_gpus, global_batch and `negatives` must say what ran."""
+    import json
+    import subprocess
+    import sys
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CTCLIP_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--small", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--lean"] + (["--local-negatives"] if local else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]                                # exactly one line on stdout: the JSON
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2 and line["warmup"] == 1
+    cfg = line["config"]
+    assert cfg["per_gpu_batch"] == 2 and cfg["global_batch"] == 4 and cfg["parallelism"] == "dp2"
+    assert cfg["negatives"] == ("local" if local else "global (all-gather)")
+    assert math.isfinite(cfg["final_loss"]) and line["value"] > 0
+    assert "rank 1 of 2: process group up (gloo)" in r.stderr

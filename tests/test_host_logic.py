@@ -238,3 +238,44 @@ def test_visualizations_scope():
     vis = Visualizations(torch.nn.Linear(2, 2), Acc())
     with pytest.raises(NotImplementedError):
         vis.visualize(visualizations=["grad_cam"])
+
+
+def test_shadow_plan_holds_its_sets_weakly():
+    """ops.PLAN (one copy launch refills every module's kernel-layout weight shadows after an optimiser step) must not keep dead
+    models alive: a ShadowSet pins its module's parameters and shadow tensors, so the plan holds the sets weakly -- dropping the
+    module's ShadowCache removes its sets from the plan and invalidates the cached all-sets table."""
+    import gc
+    from ctclip_hip import ops
+
+    class Mod:
+        def __init__(self):
+            self.w = torch.nn.Parameter(torch.randn(8, 16))
+            self.cache = ops.ShadowCache()
+
+        def shadows(self, refresh):
+            def make():
+                S = ops.ShadowSet(self.w.device)
+                S.out["w16"] = S.zeros(8, 16)
+                S.add(self.w, S.out["w16"])
+                return S
+            real = ops.PLAN.refresh
+            ops.PLAN.refresh = refresh                                 # no GPU here: the copy launch is stood in
+            try:
+                return self.cache.get_set("w", (self.w,), make)
+            finally:
+                ops.PLAN.refresh = real
+
+    launched = []
+    before = len(ops.PLAN.sets)
+    a, b = Mod(), Mod()
+    a.shadows(lambda s_, e: launched.append(s_))
+    b.shadows(lambda s_, e: launched.append(s_))
+    assert len(ops.PLAN.sets) == before + 2 and len(launched) == 2
+    ops.PLAN._all = {"stale": None}
+    set_b = b.cache._store["w"][1]
+    del a, launched
+    gc.collect()
+    assert len(ops.PLAN.sets) == before + 1 and ops.PLAN.sets[-1] is set_b       # a's set left with its module
+    assert ops.PLAN._all is None                                                  # ... and the all-sets table is rebuilt
+    ops.PLAN.unregister(set_b)
+    assert len(ops.PLAN.sets) == before
