@@ -323,11 +323,25 @@ __global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restr
     }
     const uint32_t wx[4] = {rx.x, rx.y, rx.z, rx.w}, wd[4] = {rd.x, rd.y, rd.z, rd.w};
     float u[8], du[8], dot = 0.f;
+    float renorm = inv;
+    if (x_normed) {
+      // y / (scale mult) is the unit row up to the bf16 rounding of y: divide that rounding's radial part out again, so that u
+      // is EXACTLY a unit vector and dx below is the exact gradient at a nearby point, as it is for the raw-row form
+      float nn = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x0 = __uint_as_float(wx[i] << 16) * rsc[2 * i], x1 = __uint_as_float(wx[i] & 0xffff0000u) * rsc[2 * i + 1];
+        nn += x0 * x0 + x1 * x1;
+      }
+#pragma unroll
+      for (int o = LPH >> 1; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 64);
+      renorm = nn > 0.f ? rsqrtf(nn) : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float x0 = __uint_as_float(wx[i] << 16), x1 = __uint_as_float(wx[i] & 0xffff0000u);
       const float d0 = __uint_as_float(wd[i] << 16), d1 = __uint_as_float(wd[i] & 0xffff0000u);
-      u[2 * i] = x_normed ? x0 * rsc[2 * i] : x0 * inv; u[2 * i + 1] = x_normed ? x1 * rsc[2 * i + 1] : x1 * inv;
+      u[2 * i] = x0 * (x_normed ? rsc[2 * i] * renorm : inv); u[2 * i + 1] = x1 * (x_normed ? rsc[2 * i + 1] * renorm : inv);
       du[2 * i] = d0 * scale[sub * 8 + 2 * i] * mult; du[2 * i + 1] = d1 * scale[sub * 8 + 2 * i + 1] * mult;
       acc[2 * i] += d0 * u[2 * i] * mult; acc[2 * i + 1] += d1 * u[2 * i + 1] * mult;
       dot += u[2 * i] * du[2 * i] + u[2 * i + 1] * du[2 * i + 1];

@@ -408,9 +408,12 @@ def test_ctclip_training_steps_golden():
         if s == 0:
             # gradients as left in .grad by the step: clipped by min(1, 0.5/norm) like the reference (:199-200)
             coef = min(1.0, 0.5 / (float(g["step0.grad_norm"]) + 1e-6))
-            # 7.5e-2: the query-path tensors of this toy (to_q.weight, q_scale: 16-token sequences, d_head 8 padded to 32) sit at
-            # 6.0-6.7e-2 depending on the bf16 rounding realisation; every other tensor is below 4e-2
-            grad_parity(dict(clip.named_parameters()), {k: v * 1.0 for k, v in ref_grads.items()}, 7.5e-2,
+            # 9e-2: the query / key path tensors of this toy's first spatial layer (to_q.weight, q_scale, k_scale: 16-token sequences,
+            # d_head 8 padded to 32, logits of +-8) sit at 6.0-8.5e-2 depending on the bf16 rounding REALISATION -- 6.1-6.7e-2 with
+            # the separate head-norm pass, 7.8-8.5e-2 with the normalisation in the GEMM epilogue, while over four seeds of config 1
+            # (d_head 32) the two forms are indistinguishable (mean 9.91e-3 vs 9.90e-3, max 1.28e-2 vs 1.32e-2:
+            # profiles/r05_headnorm_in_gemm.txt); every other tensor is below 4e-2
+            grad_parity(dict(clip.named_parameters()), {k: v * 1.0 for k, v in ref_grads.items()}, 9e-2,
                         "step-0 gradients vs reference")
     # post-step weights (reference: clip_grad_norm_(0.5) + Adam(lr 1.25e-5), two steps).  Adam's first steps move every
     # weight by ~lr whatever the gradient's size, so the UPDATE (final - initial) is what is compared: a wrong bias
