@@ -137,8 +137,10 @@ def gemm_work_fns():
     def lnbwd(A, B, dx, dx16, M, N, K, *rest):       # [rstd dq | dk | dv] [Wqg ; Wkv] with the LayerNorm backward in the epilogue
         return {"flops": 2.0 * M * N * K, "tag": "attn_proj",
                 "bytes": 2.0 * (M * K + N * K) + M * N * (4.0 + 2.0 + 4.0) + (2.0 * M * N if dx16 is not None else 0.0)}
+    def headnorm(A, B, C, inv, scale, M, N, K, lda, ldb, ldc, n_tok, heads, ncols, *rest):   # q / kv projection + cosine head-norm in the epilogue
+        return {"flops": 2.0 * M * N * K, "tag": "attn_proj_hn", "bytes": 2.0 * (M * K + N * K) + 2.0 * M * N + 4.0 * M * ncols / 32}
     return {"gemm_bf16": plain, "gemm_bf16_geglu": geglu, "gemm_bf16_geglu_bwd": geglu_bwd, "gemm_bf16_headmajor": headmajor,
-            "gemm_bf16_lnbwd": lnbwd}
+            "gemm_bf16_lnbwd": lnbwd, "gemm_bf16_headnorm": headnorm}
 
 
 def other_work_fns():
@@ -194,22 +196,34 @@ def attention_block_aggregate(timed2, tags, nsteps, vit_cfg, peaks):
     def add(key, items):
         for ms, w in items:
             acc[key]["ms"] += ms; acc[key]["flops"] += w["flops"]; acc[key]["launches"] += 1
-    # launches per step through ctclip_gemm_bf16: forward -- spatial layers q + out (kv goes through the head-major entry), temporal
-    # q + kv + out; backward -- the q and kv data gradients of every layer are ONE launch of ctclip_gemm_bf16_lnbwd (with the
-    # LayerNorm backward in its epilogue), which leaves the temporal layers' out-projection data gradient here (the spatial ones
-    # go through the head-major entry)
+    # launches per step.  ctclip_gemm_bf16_headnorm (round 5: the cosine head-norm in the projection's epilogue): q and kv of every
+    # layer, forward only, spatial layers first.  ctclip_gemm_bf16: the out projections (forward: spatial then temporal) and the
+    # temporal layers' out-projection data gradient (the spatial ones go through the head-major entry).  ctclip_gemm_bf16_lnbwd: the
+    # q + kv data gradients of a layer as ONE launch with the LayerNorm backward in its epilogue, temporal layers first.
     lnb = list(timed2.get("ctclip_gemm_bf16_lnbwd", {}).get("items", []))
-    nf_s, nf_t = 2 * sd, 3 * td
-    for st in per_step(plain):
-        assert len(st) == nf_s + nf_t + td, len(st)
-        add("spatial_fwd", st[:nf_s]); add("temporal_fwd", st[nf_s:nf_s + nf_t])
-        add("temporal_bwd", st[nf_s + nf_t:])
+    hn = list(timed2.get("ctclip_gemm_bf16_headnorm", {}).get("items", []))
+    if hn:
+        for st in per_step(hn):
+            assert len(st) == 2 * (sd + td), len(st)
+            add("spatial_fwd", st[:2 * sd]); add("temporal_fwd", st[2 * sd:])
+        for st in per_step(plain):
+            assert len(st) == sd + 2 * td, len(st)
+            add("spatial_fwd", st[:sd]); add("temporal_fwd", st[sd:sd + td]); add("temporal_bwd", st[sd + td:])
+        for st in per_step(hmaj):                   # spatial out-projection data gradient (backward) only
+            assert len(st) == sd, len(st)
+            add("spatial_bwd", st)
+    else:                                           # CTCLIP_HEADNORM_IN_GEMM=0: the round-4 launch pattern
+        nf_s, nf_t = 2 * sd, 3 * td
+        for st in per_step(plain):
+            assert len(st) == nf_s + nf_t + td, len(st)
+            add("spatial_fwd", st[:nf_s]); add("temporal_fwd", st[nf_s:nf_s + nf_t])
+            add("temporal_bwd", st[nf_s + nf_t:])
+        for st in per_step(hmaj):                   # spatial kv projection (forward), spatial out-projection data gradient (backward)
+            assert len(st) == 2 * sd, len(st)
+            add("spatial_fwd", st[:sd]); add("spatial_bwd", st[sd:])
     for st in per_step(lnb):                        # one per layer, temporal layers first
         assert len(st) == sd + td, len(st)
         add("temporal_bwd", st[:td]); add("spatial_bwd", st[td:])
-    for st in per_step(hmaj):                       # spatial kv projection (forward), spatial out-projection data gradient (backward)
-        assert len(st) == 2 * sd, len(st)
-        add("spatial_fwd", st[:sd]); add("spatial_bwd", st[sd:])
     for st in per_step(wgrad):                      # three weight gradients per layer, temporal layers first
         assert len(st) == 3 * (sd + td), len(st)
         add("temporal_bwd", st[:3 * td]); add("spatial_bwd", st[3 * td:])

@@ -129,6 +129,52 @@ __device__ __forceinline__ float sum_over_q4(float x) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// LDS and global accesses as INLINE ASM, for loops whose loads are consumed one or two K-steps after they were issued
+// (patch_gemm.hip): a plain C++ load that is loop-carried is, for the compiler's wait-count pass, "a load of unknown age", and it
+// waits for it with `s_waitcnt vmcnt(0)` -- which drains the LDS-DMA ring that shares the counter.  An asm access is invisible to
+// that pass; what orders it is the loop's own counted wait, and the results are only valid behind a wait that TIES the registers
+// (lds_wait / vm_wait_tied: the consumers then cannot be scheduled above it).
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_rd128(uint32_t addr) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ int lds_rd32(uint32_t addr) {
+  int r;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+__device__ __forceinline__ uint2 glb_rd64(const void* p) {
+  uint2 r;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+// s_waitcnt vmcnt(N) that the two registers pass through: their consumers stay behind it
+template <int N>
+__device__ __forceinline__ void vm_wait_tied(uint2& a, uint2& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void lgkm_wait_tied(int& a, int& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+__device__ __forceinline__ void lds_wr64(uint32_t addr, uint2 v) {
+  asm volatile("ds_write_b64 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+template <int NA, int NB>
+__device__ __forceinline__ void lds_wait(bf16x8 (&a)[NA], bf16x8 (&b)[NB]) {
+  static_assert(NA + NB <= 14, "operand count of one asm statement");
+  if constexpr (NA == 8 && NB == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                 "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : : "memory");
+  else if constexpr (NA == 4 && NB == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : : "memory");
+  else if constexpr (NA == 4 && NB == 8)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]),
+                 "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : : "memory");
+  else
+    static_assert(NA == 8 && NB == 4, "add the fragment-count combination");
+}
+
 #define G3_GLDS(gptr, ldsoff)                                                                                     \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                          \
                                    (__attribute__((address_space(3))) void*)(uintptr_t)(ldsoff), 16, 0, 0)
@@ -351,7 +397,13 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
 #pragma unroll
       for (int i = 0; i < IM; ++i) {
         __builtin_amdgcn_sched_barrier(0);
-        if (g.resid) ld_resid(i, rs[0]);           // (the f32-output form is the one the residual products use)
+        // (the f32-output form is the one the residual products use.)  Requested AND consumed on every path -- zeros without a
+        // residual: a load under `if (g.resid)` that is used under a second `if (g.resid)` is, for the compiler's wait-count
+        // pass, possibly still pending when the persistent tile loop comes round, and it then drains the whole DMA ring
+        // (`s_waitcnt vmcnt(0)`) in front of the first fragment register it overwrites -- at the top of EVERY K-step (found in round
+        // 5 in gemm3_kernel<256, 0>'s ISA; interleaved A/B on q / kv / out-dgrad / FF2-dgrad shapes: no measurable difference,
+        // profiles/r05_gemm3_epi0_drain.txt -- the requests of a K-step were issued a whole K-step earlier either way)
+        ld_resid(i, rs[0]);
         float v[2][8];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -363,7 +415,7 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
             v[h][0] += b0.x; v[h][1] += b0.y; v[h][2] += b0.z; v[h][3] += b0.w;
             v[h][4] += b1.x; v[h][5] += b1.y; v[h][6] += b1.z; v[h][7] += b1.w;
           }
-          if (g.resid) {
+          {
             const float4 r0 = rs[0][2 * h], r1 = rs[0][2 * h + 1];
             v[h][0] += r0.x; v[h][1] += r0.y; v[h][2] += r0.z; v[h][3] += r0.w;
             v[h][4] += r1.x; v[h][5] += r1.y; v[h][6] += r1.z; v[h][7] += r1.w;

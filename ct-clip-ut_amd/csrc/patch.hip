@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void patch_affine_bwd_kernel(const float* __re
                                                                const float* __restrict__ W, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ dW,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               int N, int F) {
+                                                               int N, int F, long ldg, int ncorr) {
   __shared__ float red[2][4][64];
   const int fl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int f = blockIdx.x * 64 + fl;
@@ -256,7 +256,9 @@ __global__ __launch_bounds__(256) void patch_affine_bwd_kernel(const float* __re
     const float gm = gamma[f], bt = beta ? beta[f] : 0.f;
     for (int n = rl; n < N; n += 4) {
       const long e = (long)n * F + f;
-      const float g = G[e], w = W[e], d = db ? db[n] : 0.f;
+      float g = G[(long)n * ldg + f];
+      for (int j = 0; j < ncorr; ++j) g -= G[(long)n * ldg + F + j];      // the virtual columns of ctclip_patch_wgrad_fused
+      const float w = W[e], d = db ? db[n] : 0.f;
       ag = fmaf(w, g, ag);
       ab = fmaf(w, d, ab);
       dW[e] += fmaf(g, gm, d * bt);
@@ -411,10 +413,11 @@ int ctclip_patch_affine_fold(const float* W, const float* bias, const float* gam
 }
 
 int ctclip_patch_affine_bwd(const float* G, const float* db, const float* W, const float* gamma, const float* beta, float* dW,
-                            float* dgamma, float* dbeta, int N, int F, void* stream) {
+                            float* dgamma, float* dbeta, int N, int F, long ldg, int ncorr, void* stream) {
   if (N <= 0 || F <= 0) return 0;
+  if (ncorr < 0 || ldg < F + ncorr) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(patch_affine_bwd_kernel, dim3((F + 63) / 64), dim3(256), 0, (hipStream_t)stream, G, db, W, gamma, beta,
-                     dW, dgamma, dbeta, N, F);
+                     dW, dgamma, dbeta, N, F, ldg, ncorr);
   CTCLIP_CHECK_LAUNCH();
 }
 

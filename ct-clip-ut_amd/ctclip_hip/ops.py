@@ -767,7 +767,7 @@ class AttentionFn(Function):
             fold = "wqg" in sh
             if fused:
                 G = wgrad(dq, n1, inner, dim, M)
-                hip.patch_affine_bwd(G, None, p_wq.detach(), gamma.detach(), None, gwq, gg, None, inner, dim)
+                hip.patch_affine_bwd(G, None, p_wq.detach(), gamma.detach(), None, gwq, gg, None, inner, dim, dim, 0)
                 wgrad(dkv, xb, 2 * inner, dim, M, out=gwkv)
                 dx16 = torch.empty(M, dim, dtype=BF16, device=dev) if aux.get("x16") is None else None
                 hip.gemm_bf16_lnbwd(dcat, sh["wcat"], dx, dx16, M, dim, 3 * inner, dcat.stride(0), sh["wcat"].stride(0), n1, c1, c2,
@@ -779,7 +779,7 @@ class AttentionFn(Function):
             if fold:
                 # G = dq^T xhat is the one weight-gradient product; d(Wq) = G gamma, d(gamma) = sum_n Wq G (exact, no division)
                 G = wgrad(dq, n1, inner, dim, M)
-                hip.patch_affine_bwd(G, None, p_wq.detach(), gamma.detach(), None, gwq, gg, None, inner, dim)
+                hip.patch_affine_bwd(G, None, p_wq.detach(), gamma.detach(), None, gwq, gg, None, inner, dim, dim, 0)
             else:
                 wgrad(dq, n1, inner, dim, M, out=gwq)
             dxkv = dgrad(dkv, sh["wkv"], M, 2 * inner, dim, out_dtype=BF16, wT16=sh.get("wkvT"))
@@ -918,6 +918,18 @@ class LinearF32Fn(Function):
 # ---------------------------------------------------------------------------------------------------
 # patch embedding: gather + LN(F) + Linear(F, dim) + bias + LN(dim)          ctvit.py:44-52
 # ---------------------------------------------------------------------------------------------------
+# CTCLIP_PATCH_FUSED=0 keeps the unfused chain (gather + LayerNorm kernel -> [tokens, F] bf16 operand -> GEMM) for A/B runs
+PATCH_FUSED = os.environ.get("CTCLIP_PATCH_FUSED", "1") != "0"
+
+
+def patch_embed_fusable(vol, C, Dz, Hy, Wx, pt, p, dim, tokens, sh):
+    """The geometries ctclip_patch_embed_fused / ctclip_patch_wgrad_fused take (include/ctclip_hip.h); everything else -- f32
+    volumes, odd tubelets, an embedding width other than 512 -- stays on the unfused chain."""
+    F_ = C * pt * p * p
+    return (PATCH_FUSED and vol.dtype == BF16 and dim == 512 and p % 4 == 0 and Wx % 4 == 0 and F_ % 32 == 0 and 128 <= F_ <= 4096
+            and tokens % 32 == 0 and C * Dz * Hy * Wx < 2 ** 31 and "wsum" in sh and vol.data_ptr() % 16 == 0)
+
+
 class PatchEmbedFn(Function):
     """The affine part of LayerNorm(F) is folded into the projection (include/ctclip_hip.h: ctclip_patch_affine_fold):
     z = xhat (W gamma)^T + (b + W beta).  The GEMM operand `A` is then the plain normalised tubelet row, and the backward
@@ -938,21 +950,32 @@ class PatchEmbedFn(Function):
         if not is16 and vol.dtype != F32:
             raise TypeError("volume must be float32 or bfloat16")
         ldA = pad8(F_)
-        A = torch.empty(M, ldA, dtype=BF16, device=vol.device)
-        mean1 = torch.empty(M, dtype=F32, device=vol.device)
-        rstd1 = torch.empty(M, dtype=F32, device=vol.device)
-        hip.patch_ln_fwd(vol, int(is16), None, None, A, mean1, rstd1, B, C, Dz, Hy, Wx, tpatch, patch, ldA, 1e-5)
-        z = gemm(A, sh["w"], M, dim, ldA, out_dtype=F32, bias=sh["b"])
+        fused = patch_embed_fusable(vol, C, Dz, Hy, Wx, tpatch, patch, dim, M, sh)
+        if fused:
+            # ONE pass over the volume (csrc/patch_gemm.hip): the [tokens, F] normalised operand is never written; the per-token
+            # (c, mean - c, rstd, mean) is what the backward needs to rebuild it from the volume
+            tstat = torch.empty(M, 4, dtype=F32, device=vol.device)
+            z = torch.empty(M, dim, dtype=F32, device=vol.device)
+            hip.patch_embed_fused(vol, sh["w"], sh["w"].stride(0), sh["wsum"], sh["b"], z, dim, tstat, B, C, Dz, Hy, Wx, tpatch,
+                                  patch, dim, 1e-5)
+            A = mean1 = rstd1 = vol.new_empty(0)
+        else:
+            tstat = vol.new_empty(0)
+            A = torch.empty(M, ldA, dtype=BF16, device=vol.device)
+            mean1 = torch.empty(M, dtype=F32, device=vol.device)
+            rstd1 = torch.empty(M, dtype=F32, device=vol.device)
+            hip.patch_ln_fwd(vol, int(is16), None, None, A, mean1, rstd1, B, C, Dz, Hy, Wx, tpatch, patch, ldA, 1e-5)
+            z = gemm(A, sh["w"], M, dim, ldA, out_dtype=F32, bias=sh["b"])
         _, y, mean2, rstd2 = layernorm(z, ln2w.detach(), ln2b.detach(), 1e-5, want16=False, want32=True)
-        ctx.save_for_backward(vol, A, mean1, rstd1, z, mean2, rstd2, ln2w)
-        ctx.sh, ctx.geom, ctx.dims = sh, geom, (B, C, Dz, Hy, Wx, F_, ldA, dim, M)
+        ctx.save_for_backward(vol, A, mean1, rstd1, z, mean2, rstd2, ln2w, tstat)
+        ctx.sh, ctx.geom, ctx.dims, ctx.fused = sh, geom, (B, C, Dz, Hy, Wx, F_, ldA, dim, M), fused
         ctx.params = (ln1w, ln1b, w, b, ln2w, ln2b)
         return y.reshape(B, t, h, wt, dim)
 
     @staticmethod
     @announces
     def backward(ctx, dy):
-        vol, A, mean1, rstd1, z, mean2, rstd2, ln2w = ctx.saved_tensors
+        vol, A, mean1, rstd1, z, mean2, rstd2, ln2w, tstat = ctx.saved_tensors
         sh = ctx.sh
         patch, tpatch = ctx.geom
         B, C, Dz, Hy, Wx, F_, ldA, dim, M = ctx.dims
@@ -967,11 +990,19 @@ class PatchEmbedFn(Function):
         db_now = colsum(dz)                                          # this call's sum: the folded terms below need it alone
         db, k3 = grad_slot(p_b)
         db += db_now
-        G = wgrad(dzb, A, dim, F_, M)                                # dz^T xhat, [dim, F] f32
         dw, k4 = grad_slot(p_w)
         d1w, k5 = grad_slot(p_l1w)
         d1b, k6 = grad_slot(p_l1b)
-        hip.patch_affine_bwd(G, db_now, _c(p_w.detach()), p_l1w.detach(), p_l1b.detach(), dw, d1w, d1b, dim, F_)
+        if ctx.fused:
+            # dz^T xhat with xhat rebuilt from the volume; two extra columns carry the (mean - c) rstd term (ctclip_patch_wgrad_fused)
+            G = torch.zeros(dim, F_ + 2, dtype=F32, device=dev)
+            hip.patch_wgrad_fused(vol, dzb, dzb.stride(0), tstat, G, F_ + 2, B, C, Dz, Hy, Wx, tpatch, patch, dim)
+            hip.patch_affine_bwd(G, db_now, _c(p_w.detach()), p_l1w.detach(), p_l1b.detach(), dw, d1w, d1b, dim, F_, F_ + 2, 2)
+            if ctx.needs_input_grad[0]:
+                mean1, rstd1 = tstat[:, 3].contiguous(), tstat[:, 2].contiguous()
+        else:
+            G = wgrad(dzb, A, dim, F_, M)                            # dz^T xhat, [dim, F] f32
+            hip.patch_affine_bwd(G, db_now, _c(p_w.detach()), p_l1w.detach(), p_l1b.detach(), dw, d1w, d1b, dim, F_, F_, 0)
         dvol = None
         if ctx.needs_input_grad[0]:                    # input attribution only (integrated gradients)
             dA = dgrad(dzb, sh["w"], M, dim, ldA, out_dtype=BF16, wT16=sh.get("wT"))      # d(xhat) = dz (W gamma)

@@ -79,7 +79,9 @@ class CTViT(nn.Module):
             bfold = torch.empty(N, dtype=F32, device=lin.weight.device)
             ops.hip.patch_affine_fold(lin.weight.detach().contiguous(), lin.bias.detach(), ln1.weight.detach(), ln1.bias.detach(),
                                       wg, bfold, N, F_, ldw)
-            return {"w": wg, "wT": wg.t().contiguous(), "b": bfold,
+            wT = wg.t().contiguous()
+            # wsum[n] = sum_f bf16(W gamma)[n][f]: the mean term of the fused tubelet embedding's epilogue (ctclip_patch_embed_fused)
+            return {"w": wg, "wT": wT, "b": bfold, "wsum": ops.colsum(wT),
                     "ones": torch.ones(F_, dtype=F32, device=wg.device), "zeros": torch.zeros(F_, dtype=F32, device=wg.device)}
 
         sh = self._shadow.get("patch", (lin.weight, lin.bias, ln1.weight, ln1.bias), build)

@@ -282,8 +282,35 @@ int ctclip_patch_ln_fwd(const void* volume, int volume_is_bf16, const float* gam
  * bias_folded, db and dbeta may be NULL (a LayerNorm without beta, a Linear without bias). */
 int ctclip_patch_affine_fold(const float* W, const float* bias, const float* gamma, const float* beta, void* Wg_bf16,
                              float* bias_folded, int N, int F, long ldw, void* stream);
+/* G is [N][ldg] (ldg >= F + ncorr); ncorr > 0: the columns F .. F + ncorr - 1 of a row hold a correction that is subtracted from
+ * every G[n][f] first (ctclip_patch_wgrad_fused); ncorr = 0, ldg = F: the plain product. */
 int ctclip_patch_affine_bwd(const float* G, const float* db, const float* W, const float* gamma, const float* beta, float* dW,
-                            float* dgamma, float* dbeta, int N, int F, void* stream);
+                            float* dgamma, float* dbeta, int N, int F, long ldg, int ncorr, void* stream);
+/* ---- the tubelet embedding as ONE pass over the volume (ctvit.py:44-50: Rearrange + LayerNorm(F) + Linear(F, N)) -------------
+ * Z[tokens, N] (f32) = LayerNorm(F)(tubelet) (W gamma)^T + (b + W beta) with the MFMA operand built from the raw voxels inside
+ * the GEMM (csrc/patch_gemm.hip): every voxel is read from HBM once, centred on a per-token constant c = bf16(mean of the
+ * tubelet's first p2-run) -- exactly 0 for a constant tubelet, as the reference's xhat -- and rounded to bf16 in the load
+ * block; mean and variance ride along in f32 and the epilogue applies  z = rstd (acc - (mean - c) wsum[n]) + bias_folded[n].
+ * The [tokens, F] normalised operand of ctclip_patch_ln_fwd is never written.
+ *   volume [B,C,Dz,Hy,Wx] bf16, 16-byte aligned;  Wfold_bf16 [N][ldw] and bias_folded [N] from ctclip_patch_affine_fold;
+ *   wsum[n] = sum_f Wfold[n][f] (f32, of the bf16 values);  tstat [tokens][4] f32 output: (c, mean - c, rstd, mean) per token,
+ *   what the backward needs (ctclip_patch_wgrad_fused; ctclip_patch_ln_bwd_dx takes columns 3 and 2).
+ * Geometry it takes: p % 4 == 0, Wx % 4 == 0, F = C pt p p a multiple of 32 in [128, 4096], N == 512; hipErrorInvalidValue
+ * otherwise (the host layer then keeps ctclip_patch_ln_fwd + ctclip_gemm_bf16). */
+int ctclip_patch_embed_fused(const void* volume_bf16, const void* Wfold_bf16, long ldw, const float* wsum, const float* bias_folded,
+                             float* Z, long ldz, float* tstat, int B, int C, int Dz, int Hy, int Wx, int pt, int p, int N,
+                             float eps, void* stream);
+/* The weight-gradient product of that projection, G[N][F] = dz^T xhat, with xhat RECOMPUTED from the volume (gemm4's tile and loop;
+ * the feature operand's tile is written by the load block from registers as bf16((x - c) rstd) = xhat + (mean - c) rstd):
+ *   G[n][0 .. F) (+)= sum_tokens dz[tok][n] bf16((x - c) rstd)[tok][f],    G[n][F], G[n][F + 1] (+)= sum_tokens dz[tok][n] v[tok]
+ * where v = (mean - c) rstd split into a high and a low bf16 part: ctclip_patch_affine_bwd (ncorr = 2) subtracts G[n][F] + G[n][F + 1]
+ * from every G[n][f] and gets d(W), d(gamma), d(beta) as before.  dz [tokens, lddz] bf16 (the LayerNorm(N) backward's bf16
+ * copy), tstat from ctclip_patch_embed_fused, G [N][ldg] f32 with ldg == F + 2, accumulated into (the caller zeroes it); the
+ * tokens are split over the workgroups, partial tiles go through splitk_ws and are summed in split order (reproducible).
+ * Same geometry as the forward, tokens % 32 == 0, N % 8 == 0. */
+int ctclip_patch_wgrad_fused(const void* volume_bf16, const void* dz_bf16, long lddz, const float* tstat, float* G, long ldg, int B,
+                             int C, int Dz, int Hy, int Wx, int pt, int p, int N, float* splitk_ws, long splitk_ws_floats,
+                             void* stream);
 /* d(volume) [B,C,Dz,Hy,Wx] f32 of the gather + LayerNorm above (input attribution: integrated gradients,
  * src/utils/visualizations.py:851-910; training never needs it). */
 int ctclip_patch_ln_bwd_dx(const void* volume, int volume_is_bf16, const void* dA_bf16, long ldd, const float* gamma,

@@ -984,6 +984,113 @@ def test_patch_ln_forward_and_volume_gradient(hip, in16, geom):
     check("patch ln d(volume)", dvol, vr.grad, 2e-5)
 
 
+def tubelet_rows(vol, pt, p):
+    """[B,C,Dz,Hy,Wx] -> [tokens, C pt p p] in the reference's feature order (ctvit.py:45: 'b c (t pt) (h p1) (w p2) -> b t h w (c pt p1 p2)')"""
+    B, C, Dz, Hy, Wx = vol.shape
+    t, h, w = Dz // pt, Hy // p, Wx // p
+    return vol.reshape(B, C, t, pt, h, p, w, p).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B * t * h * w, C * pt * p * p)
+
+
+@pytest.mark.parametrize("geom", [(1, 1, 20, 40, 480, 10, 20),     # production tubelet (F = 4000, 24 tokens per row), 96 tokens: one ragged tile
+                                  (2, 1, 40, 80, 480, 10, 20),     # 768 tokens = 6 whole tiles, two volumes
+                                  (3, 2, 16, 32, 64, 8, 8),        # two channels, F = 1024, 192 tokens (1.5 tiles)
+                                  (1, 1, 32, 48, 48, 16, 16)])     # F = 4096: the largest piece table, 18 tokens
+def test_patch_embed_fused_forward(hip, geom):
+    """ctclip_patch_embed_fused (csrc/patch_gemm.hip): Rearrange + LayerNorm(F) + Linear(F, 512) of reference ctvit.py:44-50 with
+    the MFMA operand built from the raw voxels inside the GEMM -- against f32 torch (LayerNorm over the tubelet rows, then the
+    folded bf16 weight), the row statistics against torch's, and CONSTANT tubelets (air = -1 padding: the reference's xhat is
+    exactly 0 there) must come out as the folded bias, bit for bit."""
+    B, C, Dz, Hy, Wx, pt, p = geom
+    N, F_ = 512, C * pt * p * p
+    vol = bf((rnd(B, C, Dz, Hy, Wx, seed=400) * 0.5 + 0.1).clamp(-1, 1))
+    vol[0, :, :pt, :p, : 3 * p] = -1.0                               # three constant tubelets
+    vol[-1, :, -pt:, -p:, -p:] = 0.375                               # and the very last token
+    W, b = rnd(N, F_, seed=401) * (F_ ** -0.5), rnd(N, seed=402) * 0.05
+    gm, bt = 1 + 0.2 * rnd(F_, seed=403), 0.1 * rnd(F_, seed=404)
+    Wg, bfold = torch.empty(N, F_, device=DEV, dtype=torch.bfloat16), torch.empty(N, device=DEV)
+    hip.patch_affine_fold(W, b, gm, bt, Wg, bfold, N, F_, F_)
+    wsum = Wg.float().sum(1).contiguous()
+    rows = tubelet_rows(vol.float(), pt, p)
+    M = rows.shape[0]
+    xhat = torch.nn.functional.layer_norm(rows, (F_,), None, None, 1e-5)
+    ref = xhat @ Wg.float().t() + bfold
+    Z = torch.full((M, N), 7.0, device=DEV)
+    tstat = torch.empty(M, 4, device=DEV)
+    hip.patch_embed_fused(vol, Wg, F_, wsum, bfold, Z, N, tstat, B, C, Dz, Hy, Wx, pt, p, N, 1e-5)
+    cbase, mup, rstd, mean = tstat.unbind(1)
+    assert torch.equal(mean, cbase + mup)
+    check(f"fused tubelet embedding {geom}", Z, ref, 1e-2)
+    check("tubelet mean", mean, rows.mean(1), 1e-5)
+    check("tubelet rstd", rstd, (rows.var(1, unbiased=False) + 1e-5).rsqrt(), 1e-4)
+    const = rows.std(1) == 0
+    assert int(const.sum()) >= 4
+    assert torch.equal(Z[const], bfold[None].expand(int(const.sum()), N))           # xhat = 0 exactly: z is the folded bias
+    assert torch.equal(cbase[const], rows[const][:, 0]) and torch.equal(mean[const], rows[const][:, 0])
+    # against the unfused chain on the same operands (gather + LayerNorm kernel -> bf16 operand -> GEMM): same rounding budget
+    A = torch.empty(M, F_, device=DEV, dtype=torch.bfloat16)
+    m2, r2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.patch_ln_fwd(vol, 1, None, None, A, m2, r2, B, C, Dz, Hy, Wx, pt, p, F_, 1e-5)
+    Z2 = torch.empty(M, N, device=DEV)
+    hip.gemm_bf16(A, Wg, Z2, bfold, None, M, N, F_, F_, F_, N, 0, 1, 1, 1, 1, 0, 1.0, 0)
+    e_fused, e_chain = relerr(Z, ref), relerr(Z2, ref)
+    print(f"  error vs f32: fused {e_fused:.3e}, unfused chain {e_chain:.3e}")
+    assert e_fused <= 1.5 * e_chain + 1e-4
+    # geometry the kernel does not take: refused before anything is launched
+    with pytest.raises(RuntimeError):
+        hip.patch_embed_fused(vol, Wg, F_, wsum, bfold, Z, N, tstat, B, C, Dz, Hy, Wx, pt, p, 256, 1e-5)
+
+
+@pytest.mark.parametrize("geom", [(4, 1, 20, 40, 480, 10, 20),     # production tubelet: F + 2 = 4002 columns = 16 feature windows (the last one ragged, with
+                                  #                                  the two virtual columns), 384 tokens = 12 K-steps
+                                  (8, 1, 40, 80, 480, 10, 20),     # 3072 tokens: the tokens are split over several workgroups per tile
+                                  (6, 2, 16, 32, 64, 8, 8),        # two channels, F = 1024 (the virtual columns open a window of their own)
+                                  (32, 1, 32, 48, 48, 16, 16)])    # F = 4096, 576 tokens
+def test_patch_wgrad_fused(hip, geom):
+    """ctclip_patch_wgrad_fused + ctclip_patch_affine_bwd(ncorr = 2): the tubelet projection's weight-gradient product with the
+    normalised operand rebuilt from the volume (reference ctvit.py:49-50 backward) -- G = dz^T xhat against f32 torch, then d(W),
+    d(gamma), d(beta) against autograd of the unfolded expression; constant tubelets contribute exactly nothing; two runs agree
+    bit for bit (partial tiles summed in split order)."""
+    B, C, Dz, Hy, Wx, pt, p = geom
+    N, F_ = 512, C * pt * p * p
+    vol = bf((rnd(B, C, Dz, Hy, Wx, seed=410) * 0.5 + 0.1).clamp(-1, 1))
+    vol[0, :, :pt, :p, : 2 * p] = -1.0
+    W, b = rnd(N, F_, seed=411) * (F_ ** -0.5), rnd(N, seed=412) * 0.05
+    gm, bt = 1 + 0.2 * rnd(F_, seed=413), 0.1 * rnd(F_, seed=414)
+    Wg, bfold = torch.empty(N, F_, device=DEV, dtype=torch.bfloat16), torch.empty(N, device=DEV)
+    hip.patch_affine_fold(W, b, gm, bt, Wg, bfold, N, F_, F_)
+    rows = tubelet_rows(vol.float(), pt, p)
+    M = rows.shape[0]
+    Z, tstat = torch.empty(M, N, device=DEV), torch.empty(M, 4, device=DEV)
+    hip.patch_embed_fused(vol, Wg, F_, Wg.float().sum(1).contiguous(), bfold, Z, N, tstat, B, C, Dz, Hy, Wx, pt, p, N, 1e-5)
+    dz = bf(rnd(M, N, seed=415))
+    xhat = torch.nn.functional.layer_norm(rows, (F_,), None, None, 1e-5)
+    G_ref = dz.float().t() @ xhat
+    Gx = torch.zeros(N, F_ + 2, device=DEV)
+    hip.patch_wgrad_fused(vol, dz, N, tstat, Gx, F_ + 2, B, C, Dz, Hy, Wx, pt, p, N)
+    G = Gx[:, :F_] - (Gx[:, F_] + Gx[:, F_ + 1])[:, None]
+    check(f"G = dz^T xhat from the volume {geom}", G, G_ref, 1e-2)
+    Gx2 = torch.zeros_like(Gx)
+    hip.patch_wgrad_fused(vol, dz, N, tstat, Gx2, F_ + 2, B, C, Dz, Hy, Wx, pt, p, N)
+    assert torch.equal(Gx, Gx2)
+    # constant tubelets: zero rows of the operand -- dropping them from dz changes nothing
+    const = rows.std(1) == 0
+    assert int(const.sum()) >= 2
+    dz0 = dz.clone()
+    dz0[const] = 0
+    Gx3 = torch.zeros_like(Gx)
+    hip.patch_wgrad_fused(vol, dz0, N, tstat, Gx3, F_ + 2, B, C, Dz, Hy, Wx, pt, p, N)
+    assert torch.equal(Gx3, Gx)
+    # the parameter gradients out of it, against autograd of z = (xhat gamma + beta) W^T + b
+    Wr, gr, btr = (t.clone().requires_grad_(True) for t in (W, gm, bt))
+    ((xhat * gr + btr) @ Wr.t()).backward(dz.float())
+    db = dz.float().sum(0)
+    dW, dg, dbt = torch.zeros(N, F_, device=DEV), torch.zeros(F_, device=DEV), torch.zeros(F_, device=DEV)
+    hip.patch_affine_bwd(Gx, db, W, gm, bt, dW, dg, dbt, N, F_, F_ + 2, 2)
+    check("d(W)", dW, Wr.grad, 1e-2)
+    check("d(gamma)", dg, gr.grad, 1.5e-2)
+    check("d(beta)", dbt, btr.grad, 1e-4)
+
+
 @pytest.mark.parametrize("N,F_,M", [(24, 40, 96), (64, 4000, 200), (16, 8, 50)])
 def test_patch_affine_fold_and_backward(hip, N, F_, M):
     """ctclip_patch_affine_fold / _bwd: LayerNorm(F)'s gamma / beta folded into the tubelet projection (reference
@@ -1006,7 +1113,7 @@ def test_patch_affine_fold_and_backward(hip, N, F_, M):
     check("folded forward", xhat @ (W * gm).t() + (b + W @ bt), z.detach(), 1e-5)
     G, db = dz.t() @ xhat, dz.sum(0)
     dW, dg, dbt = torch.ones(N, F_, device=DEV), torch.ones(F_, device=DEV), torch.ones(F_, device=DEV)   # accumulate on top
-    hip.patch_affine_bwd(G.contiguous(), db, W, gm, bt, dW, dg, dbt, N, F_)
+    hip.patch_affine_bwd(G.contiguous(), db, W, gm, bt, dW, dg, dbt, N, F_, F_, 0)
     check("d(W)", dW - 1, Wr.grad, 1e-5)
     check("d(gamma)", dg - 1, gr.grad, 1e-5)
     check("d(beta)", dbt - 1, btr.grad, 1e-5)

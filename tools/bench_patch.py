@@ -30,5 +30,5 @@ if os.environ.get("NULL_AFFINE", "1") == "1":
         print("patch_ln_fwd without affine: not supported by this build", type(e).__name__)
 G, W = torch.randn(512, F_, device="cuda"), torch.randn(512, F_, device="cuda")
 dW, dbv = torch.zeros(512, F_, device="cuda"), torch.randn(512, device="cuda")
-t = timeit(lambda: hip.patch_affine_bwd(G, dbv, W, gm, bt, dW, dg, db, 512, F_))
+t = timeit(lambda: hip.patch_affine_bwd(G, dbv, W, gm, bt, dW, dg, db, 512, F_, F_, 0))
 print(f"patch_affine_bwd {t:9.1f} us (folded d(W) / d(gamma) / d(beta) of LayerNorm(4000): no pass over the tokens)")
