@@ -1044,7 +1044,8 @@ def test_patch_embed_fused_forward(hip, geom):
                                   #                                  the two virtual columns), 384 tokens = 12 K-steps
                                   (8, 1, 40, 80, 480, 10, 20),     # 3072 tokens: the tokens are split over several workgroups per tile
                                   (6, 2, 16, 32, 64, 8, 8),        # two channels, F = 1024 (the virtual columns open a window of their own)
-                                  (32, 1, 32, 48, 48, 16, 16)])    # F = 4096, 576 tokens
+                                  (32, 1, 32, 48, 48, 16, 16),     # F = 4096, 576 tokens
+                                  (2, 1, 240, 480, 480, 10, 20)])  # two production volumes: 27 648 tokens, 864 K-steps in 8 splits
 def test_patch_wgrad_fused(hip, geom):
     """ctclip_patch_wgrad_fused + ctclip_patch_affine_bwd(ncorr = 2): the tubelet projection's weight-gradient product with the
     normalised operand rebuilt from the volume (reference ctvit.py:49-50 backward) -- G = dz^T xhat against f32 torch, then d(W),
