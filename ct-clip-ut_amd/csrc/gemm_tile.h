@@ -145,6 +145,10 @@ __device__ __forceinline__ int lds_rd32(uint32_t addr) {
   asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(addr));
   return r;
 }
+// NOTE for every user: the compiler believes the result is valid the moment the asm has been issued.  Nothing may touch it before
+// the tied wait -- and that includes register COPIES the allocator inserts on its own (at a loop's entry, around a second asm's
+// tied operands).  After every change of a kernel that keeps such registers in flight, read its ISA: no v_mov of them between the
+// load and the wait (patch_gemm.hip states what was checked).
 __device__ __forceinline__ uint2 glb_rd64(const void* p) {
   uint2 r;
   asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory");

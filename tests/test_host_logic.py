@@ -279,3 +279,23 @@ def test_shadow_plan_holds_its_sets_weakly():
     assert ops.PLAN._all is None                                                  # ... and the all-sets table is rebuilt
     ops.PLAN.unregister(set_b)
     assert len(ops.PLAN.sets) == before
+
+
+def test_no_read_of_registers_an_asm_load_has_in_flight(tmp_path):
+    """csrc/patch_gemm.hip keeps registers loaded by inline-asm global loads in flight across K-steps (the volume pieces of the
+    fused tubelet embedding and of its weight gradient).  The compiler believes an asm output is valid at once, so a register copy
+    it inserts between the load and the tied `s_waitcnt` would read garbage -- silently.  Compile the file for gfx950 and scan both
+    kernels' ISA (tools/check_inflight.py): no instruction may read such a register before the wait that covers the load."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "ct-clip-ut_amd", "csrc", "patch_gemm.hip")
+    out = str(tmp_path / "patch_gemm.s")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-std=c++17", "-Wno-unused-value",
+                        "--cuda-device-only", "-S", "-o", out, src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for kernel in ("patch_gemm_fwd_kernel", "patch_wgrad_kernel"):
+        c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight.py"), out, kernel], capture_output=True, text=True)
+        assert c.returncode == 0, c.stdout[-2000:]
