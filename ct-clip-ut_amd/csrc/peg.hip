@@ -508,6 +508,175 @@ __global__ __launch_bounds__(WG_MAXT * WG_C2 / 8, 3) void peg_wgrad_plane_kernel
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Data AND weight gradient in one pass over dy (round 5).  Both are sums over the SAME 27 neighbours of dy:
+//     dx[t,h,w]       = [dy[t,h,w]] + sum_taps w27[kt,kh,kw] N(kt,kh,kw),        N = dy[t - kt + 2, h - kh + 1, w - kw + 1]
+//     dw27[kt,kh,kw] += x[t,h,w] N(kt,kh,kw)                 (the weight gradient re-indexed onto the position of x),  dbias += dy
+// so with the ring of the weight-gradient kernel holding the dy planes t, t+1, t+2 (instead of x planes t-2 .. t) and the thread's
+// own x values in registers, every LDS read of a neighbour feeds two multiply-adds: one into dx, one into the tap's sum.  The
+// separate data-gradient sweep -- a second read of dy and 6.9 GB of the 12.4 GB the two kernels moved per call at 96 pairs -- is
+// gone; the 27 weights of the slice sit in LDS behind the ring (read as broadcasts).  Same decomposition as
+// peg_wgrad_plane_kernel: a workgroup owns a 16-channel slice and a chunk of batch items, one thread = 2 channels x PL_P
+// positions, partial sums of the chunk leave as one row of `partials`.
+// Shape: one thread = 2 channels x FP = 12 consecutive w positions (the 24-wide CT-ViT grid = 2 strips), 384 threads for 24 rows x 2
+// strips x 8 channel pairs -- at most two waves per SIMD, i.e. 256 registers: the 28 + 12 running sums, the thread's own x and the
+// two planes in flight need ~190 (with 6 positions per thread and 768 threads the same kernel spilled 164 registers at the 168 it
+// may use).  A wider thread also reads less: 14 neighbour reads + 3 weights per 12 outputs and (kt, kh) instead of 8 + 3 per 6.
+// Image rows as in plane_pitch(): one unused column between strips, and the pitch padded to 2 (mod 4) position blocks so that the
+// (row, strip) pairs of one LDS pass sit on different bank groups.
+constexpr int FP = 12;
+__host__ __device__ inline int fused_pitch(int strips) { int p = strips * (FP + 1) + 3; while ((p & 3) != 2) ++p; return p; }
+__host__ __device__ constexpr int fused_tap(int i) { return i == 0 ? 0 : (i <= FP ? i + 1 : FP + 3); }
+constexpr int FUSED_MAXT = 512;
+
+template <int WG_C2>
+__global__ __launch_bounds__(FUSED_MAXT, 2) void peg_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ w27, float* __restrict__ dx,
+                                                               bf16_t* __restrict__ dx16, float* __restrict__ partials, Grid5 g,
+                                                               int strips, int bchunk, int residual) {
+  extern __shared__ __attribute__((aligned(16))) f32x2 wg_smem[];
+  const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int d2 = g.d4 * 2;
+  const int nslices = d2 / WG_C2;
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = blk % nslices;
+  const long b0 = (long)(blk / nslices) * bchunk, b1 = (b0 + bchunk < g.B) ? b0 + bchunk : g.B;
+  const int c2 = tid & (WG_C2 - 1), sid = tid / WG_C2;
+  const int h_ = sid / strips, strip = sid % strips, w0 = strip * FP;
+  const bool active = h_ < g.H;
+  const int pitch = fused_pitch(strips);
+  const int plane_f2 = (g.H + 2) * pitch * WG_C2;
+  f32x2* ring = wg_smem;                                     // [3][(H+2)][pitch][WG_C2]: dy planes t, t+1, t+2
+  f32x2* wl = wg_smem + 3 * plane_f2;                        // [27][WG_C2]
+  const f32x2 zero = {0.f, 0.f};
+  for (int i = tid; i < 3 * plane_f2; i += nthreads) ring[i] = zero;
+  const int c = slice * WG_C2 + c2;                          // float2 column of this thread
+  for (int i = tid; i < 27 * WG_C2; i += nthreads) wl[i] = ((const f32x2*)w27)[(i / WG_C2) * d2 + slice * WG_C2 + (i % WG_C2)];
+  const f32x2* xv = (const f32x2*)x;
+  const f32x2* dv = (const f32x2*)dy;
+  f32x2 acc[28];
+#pragma unroll
+  for (int i = 0; i < 28; ++i) acc[i] = zero;
+  const int own = ((h_ + 1) * pitch + w0 + strip + 2) * WG_C2 + c2;  // this thread's first interior position inside a plane
+
+  f32x2 xcur[FP], xnext[FP], dnext[FP];
+  const uint32_t poff = (uint32_t)((h_ * g.W + w0) * d2 + c);
+  const long plane_elems = (long)g.H * g.W * d2;
+  auto load_plane = [&](const f32x2* src, long b, int t, f32x2 (&dst)[FP]) {      // t >= T: zeros (the planes past the end)
+    const f32x2* base = src + (b * g.T + (t < g.T ? t : 0)) * plane_elems;
+#pragma unroll
+    for (int i = 0; i < FP; ++i) dst[i] = (active && t < g.T && w0 + i < g.W) ? base[poff + (uint32_t)(i * d2)] : zero;
+  };
+  auto put = [&](int slot, const f32x2 (&v)[FP]) {         // into the ring; the bias gradient sums every dy element once, here
+    if (!active) return;
+    f32x2* dst = ring + slot * plane_f2 + own;
+#pragma unroll
+    for (int i = 0; i < FP; ++i) { dst[i * WG_C2] = v[i]; acc[27] += v[i]; }
+  };
+  __syncthreads();                                           // zero fill + weights visible (borders stay zero for good)
+
+  for (long b = b0; b < b1; ++b) {
+    lds_only_barrier();                                      // the previous item's planes are no longer read
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {                            // dy planes 0, 1, 2
+      load_plane(dv, b, s, dnext);
+      put(s, dnext);
+    }
+    load_plane(xv, b, 0, xcur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < FP; ++i) asm volatile("" : "+v"(xcur[i]));
+    lds_only_barrier();
+    for (int t = 0; t < g.T; ++t) {
+      load_plane(dv, b, t + 3, dnext);                       // in flight while this plane is consumed
+      load_plane(xv, b, t + 1, xnext);
+      f32x2 dxa[FP];
+#pragma unroll
+      for (int i = 0; i < FP; ++i) dxa[i] = zero;
+      int wofs = 0;
+      asm volatile("" : "+s"(wofs));                         // opaque zero: keeps the 27 weight reads inside the loop
+      const f32x2* wk = wl + wofs;
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const f32x2* pb = ring + ((t + 2 - kt) % 3) * plane_f2;      // dy plane t - kt + 2
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const f32x2* prow = pb + ((h_ + 2 - kh) * pitch + w0 + strip) * WG_C2 + c2;       // row h - kh + 1
+          f32x2 xs[FP + 2];
+#pragma unroll
+          for (int i = 0; i < FP + 2; ++i) xs[i] = prow[fused_tap(i) * WG_C2];
+          if (residual && kt == 2 && kh == 1) {              // N(2,1,1) is dy[t,h,w] itself: the residual path
+#pragma unroll
+            for (int i = 0; i < FP; ++i) dxa[i] += xs[i + 1];
+          }
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const f32x2 wt = wk[((kt * 3 + kh) * 3 + kw) * WG_C2 + c2];
+            f32x2 a = acc[(kt * 3 + kh) * 3 + kw];
+#pragma unroll
+            for (int i = 0; i < FP; ++i) {                 // neighbour w - kw + 1 of output i sits at padded column i + 2 - kw
+              const f32x2 nb = xs[i + 2 - kw];
+              dxa[i] += wt * nb;
+              a += xcur[i] * nb;
+            }
+            acc[(kt * 3 + kh) * 3 + kw] = a;
+          }
+          // pin the step (see peg_plane_kernel): both sets of sums, or the compiler issues every LDS read of the plane up front
+          asm volatile("" : "+v"(acc[(kt * 3 + kh) * 3 + 0]), "+v"(acc[(kt * 3 + kh) * 3 + 1]), "+v"(acc[(kt * 3 + kh) * 3 + 2]) : : "memory");
+#pragma unroll
+          for (int i = 0; i < FP; ++i) asm volatile("" : "+v"(dxa[i]) : : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // the loads of this step are waited for HERE (see peg_wgrad_plane_kernel) -- before this step's stores are issued, so that
+      // the wait does not drain stores: they go out last and retire under the next step's arithmetic
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < FP; ++i) asm volatile("" : "+v"(xnext[i]), "+v"(dnext[i]));
+      lds_only_barrier();                                    // everybody is done with dy plane t
+      put(t % 3, dnext);                                     // dy plane t + 3 takes its slot
+      lds_only_barrier();
+#pragma unroll
+      for (int i = 0; i < FP; ++i) xcur[i] = xnext[i];
+      if (active) {                                          // dx[t] (f32 and its bf16 mirror)
+        const long o0 = (b * g.T + t) * plane_elems + poff;
+#pragma unroll
+        for (int i = 0; i < FP; ++i) {
+          if (w0 + i >= g.W) continue;
+          if (dx) ((f32x2*)dx)[o0 + (uint32_t)(i * d2)] = dxa[i];
+          if (dx16) ((uint32_t*)dx16)[o0 + (uint32_t)(i * d2)] = pack_bf16x2(dxa[i][0], dxa[i][1]);
+        }
+      }
+    }
+  }
+
+  // reduce the 28 partial sums over the threads that share a channel pair: lanes l ^ {WG_C2 .. 32}, then the waves
+#pragma unroll
+  for (int i = 0; i < 28; ++i) {
+#pragma unroll
+    for (int o = WG_C2; o < 64; o <<= 1) {
+      f32x2 v = acc[i];
+      v[0] = __shfl_xor(v[0], o, 64); v[1] = __shfl_xor(v[1], o, 64);
+      acc[i] += v;
+    }
+  }
+  __syncthreads();                                           // ring is free
+  f32x2* red = wg_smem;                                      // [waves][WG_C2][28]
+  if (lane < WG_C2) {
+#pragma unroll
+    for (int i = 0; i < 28; ++i) red[(wave * WG_C2 + lane) * 28 + i] = acc[i];
+  }
+  __syncthreads();
+  const int nwaves = nthreads >> 6;
+  for (int idx = tid; idx < WG_C2 * 28; idx += nthreads) {
+    const int rc = idx / 28, i = idx % 28;
+    f32x2 sum = zero;
+    for (int wv = 0; wv < nwaves; ++wv) sum += red[(wv * WG_C2 + rc) * 28 + i];
+    float* dst = partials + ((long)(blk / nslices) * 28 + i) * (d2 * 2) + (slice * WG_C2 + rc) * 2;
+    dst[0] = sum[0]; dst[1] = sum[1];
+  }
+}
+
 inline int wgrad_plane_threads(int H, int W, int d, int WG_C2, int* strips, size_t* lds) {
   if (CTCLIP_KNOB("CTCLIP_PEG_SWEEP")) return 0;
   if ((d / 4) % PL_CG) return 0;
@@ -578,6 +747,52 @@ int ctclip_peg_bwd_data(const float* dy, const float* w27, float* dx, void* dx_b
   hipLaunchKernelGGL(peg_sweep_kernel<false>, dim3(grid_for(B * H * ((W + PEG_CW - 1) / PEG_CW) * g.d4)), dim3(256), lds,
                      (hipStream_t)stream, dy, w27, (const float*)nullptr, dx, (bf16_t*)dx_bf16, g, residual);
   CTCLIP_CHECK_LAUNCH();
+}
+
+// data + weight + bias gradient in ONE pass over dy (peg_bwd_fused_kernel); hipErrorInvalidValue when the grid does not take the
+// plane tiling (the caller then runs ctclip_peg_bwd_data and ctclip_peg_bwd_weight)
+int ctclip_peg_bwd_fused(const float* dy, const float* x, const float* w27, float* dx, void* dx_bf16, float* dw27, float* dbias,
+                         long B, int T, int H, int W, int d, int residual, float* partials, void* stream) {
+  const long npos = B * T * H * W;
+  if (npos <= 0) return 0;
+  if ((d & 3) || d / 4 > 256 || !partials || !dx) return (int)hipErrorInvalidValue;
+  Grid5 g{B, T, H, W, d / 4};
+  hipStream_t st = (hipStream_t)stream;
+  constexpr int c2 = 8;
+  if ((d / 4) % PL_CG) return (int)hipErrorInvalidValue;
+  const int strips = (W + FP - 1) / FP;
+  const int threads = (H * strips * c2 + 63) / 64 * 64;
+  if (threads > FUSED_MAXT) return (int)hipErrorInvalidValue;
+  size_t plds = ((size_t)3 * (H + 2) * fused_pitch(strips) * c2 + 27 * c2) * sizeof(float2);   // the dy ring + the slice's 27 weights
+  const size_t red = (size_t)(threads / 64) * c2 * 28 * sizeof(float2);
+  if (plds < red) plds = red;
+  if (plds > (size_t)160 * 1024) return (int)hipErrorInvalidValue;
+  const long rowf = 28L * d;
+  const int ncu = ctclip_cu_count8();
+  const int nslices = 2 * g.d4 / c2;
+  // batch items per workgroup: as ctclip_peg_bwd_weight (one workgroup per CU, the chunking with the fewest item-times)
+  const long slots = (long)ncu;
+  const long cap = kPartialsFloats / rowf;
+  long bchunk = B, best = -1;
+  for (int r : {2, 1, 3, 4}) {
+    long nc = (r * slots) / nslices;
+    if (nc > cap) nc = cap;
+    if (nc < 1) nc = 1;
+    if (nc > B) nc = B;
+    const long bc = (B + nc - 1) / nc;
+    nc = (B + bc - 1) / bc;
+    const long cost = ((nc * nslices + slots - 1) / slots) * bc;
+    if (best < 0 || cost < best) { best = cost; bchunk = bc; }
+  }
+  const long nchunks = (B + bchunk - 1) / bchunk;
+  if (plds > 65536) hipFuncSetAttribute((const void*)peg_bwd_fused_kernel<c2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);
+  hipLaunchKernelGGL(peg_bwd_fused_kernel<c2>, dim3((unsigned)(nchunks * nslices)), dim3(threads), plds, st, dy, x, w27, dx,
+                     (bf16_t*)dx_bf16, partials, g, strips, (int)bchunk, residual);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  int r = ctclip_reduce_partials(partials, (int)nchunks, rowf, 27 * d, dw27, st);
+  if (r == 0) r = ctclip_reduce_partials(partials + 27L * d, (int)nchunks, rowf, d, dbias, st);
+  return r;
 }
 
 int ctclip_peg_bwd_weight(const float* dy, const float* x, float* dw27, float* dbias, long B, int T, int H, int W, int d,

@@ -495,6 +495,23 @@ class LayerNormFn(Function):
 # ---------------------------------------------------------------------------------------------------
 # PEG
 # ---------------------------------------------------------------------------------------------------
+def peg_fused_ok(h, w, d):
+    """Grids ctclip_peg_bwd_fused takes (csrc/peg.hip: 12 positions per thread, 8 channel pairs per workgroup, three dy planes in LDS)."""
+    if d % 16:
+        return False
+    strips = (w + 11) // 12
+    threads = (h * strips * 8 + 63) // 64 * 64
+    pitch = strips * 13 + 3
+    while pitch % 4 != 2:
+        pitch += 1
+    lds = (3 * (h + 2) * pitch * 8 + 27 * 8) * 8
+    return threads <= 512 and lds <= 160 * 1024
+
+
+# CTCLIP_PEG_FUSED=0 keeps the two backward kernels (A/B runs)
+PEG_FUSED = os.environ.get("CTCLIP_PEG_FUSED", "1") != "0"
+
+
 class PegFn(Function):
     """attention.py:55-83 (+ the residual of :325 when `residual`)."""
 
@@ -524,21 +541,28 @@ class PegFn(Function):
         dyc = _c(dy)
         dx = torch.empty_like(dyc)
         dx16 = torch.empty(dyc.shape, dtype=BF16, device=dyc.device)
-        hip.peg_bwd_data(dyc, w27, dx, dx16, b, t, h, w, d, residual)
+        fused = PEG_FUSED and peg_fused_ok(h, w, d)                # data + weight gradient in one pass over dy
+        if not fused:
+            hip.peg_bwd_data(dyc, w27, dx, dx16, b, t, h, w, d, residual)
         _tag16(dx, dx16)
         p_w, p_b = ctx.params
         gw, dw_direct = grad_slot(p_w, note=False)
         gb, db_direct = grad_slot(p_b, note=False)
+        dw27 = torch.zeros(27, d, dtype=F32, device=dy.device)
         if dw_direct and db_direct:
             _issued.extend(q for q in (p_w, p_b) if getattr(q, "_ctclip_sync", None) is not None)
             # the tap-major result is folded into the [d,1,3,3,3] gradient in place
-            dw27 = torch.zeros(27, d, dtype=F32, device=dy.device)
-            hip.peg_bwd_weight(dyc, xc, dw27, gb, b, t, h, w, d)
+            if fused:
+                hip.peg_bwd_fused(dyc, xc, w27, dx, dx16, dw27, gb, b, t, h, w, d, residual)
+            else:
+                hip.peg_bwd_weight(dyc, xc, dw27, gb, b, t, h, w, d)
             gw.view(d, 27).add_(dw27.t())
             return dx, None, None, None, None
-        dw27 = torch.zeros(27, d, dtype=F32, device=dy.device)
         db = torch.zeros(d, dtype=F32, device=dy.device)
-        hip.peg_bwd_weight(dyc, xc, dw27, db, b, t, h, w, d)
+        if fused:
+            hip.peg_bwd_fused(dyc, xc, w27, dx, dx16, dw27, db, b, t, h, w, d, residual)
+        else:
+            hip.peg_bwd_weight(dyc, xc, dw27, db, b, t, h, w, d)
         return dx, dw27.t().reshape(d, 1, 3, 3, 3), db, None, None
 
 

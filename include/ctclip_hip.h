@@ -266,6 +266,14 @@ int ctclip_peg_bwd_data(const float* dy, const float* w27, float* dx, void* dx_b
 int ctclip_peg_bwd_weight(const float* dy, const float* x, float* dw27, float* dbias, long B, int T, int H, int W, int d,
                           float* partials, void* stream);
 
+/* ctclip_peg_bwd_data and ctclip_peg_bwd_weight in ONE pass over dy (attention.py:55-83 backward): both gradients are sums over
+ * the same 27 neighbours of dy -- dx[t,h,w] = [dy] + sum w27[tap] N(tap), dw27[tap] += x[t,h,w] N(tap), N(kt,kh,kw) = dy[t-kt+2,
+ * h-kh+1, w-kw+1] -- so with the dy planes t, t+1, t+2 in LDS and x in registers each neighbour read feeds both.  dx / dx_bf16 as
+ * ctclip_peg_bwd_data, dw27 / dbias accumulated as ctclip_peg_bwd_weight (two-stage, reproducible).  Takes the grids the plane
+ * tiling takes (e.g. the CT-ViT's 24 x 24, d % 16 == 0); hipErrorInvalidValue otherwise. */
+int ctclip_peg_bwd_fused(const float* dy, const float* x, const float* w27, float* dx, void* dx_bf16, float* dw27, float* dbias,
+                         long B, int T, int H, int W, int d, int residual, float* partials, void* stream);
+
 /* ---- tubelet gather + LayerNorm(c*pt*p*p) -> bf16 GEMM operand [tokens, ldA] (ctvit.py:44-49) ----
  * volume: [B,C,Dz,Hy,Wx] f32 or bf16; pad columns F..ldA-1 are written as zero.  gamma == NULL (then beta is ignored): the
  * plain normalised rows, for callers that fold the affine part into the projection (ctclip_patch_affine_fold). */

@@ -1124,6 +1124,7 @@ def test_patch_affine_fold_and_backward(hip, N, F_, M):
 @pytest.mark.parametrize("B,T,H,W,d", [
     (2, 5, 24, 24, 32),      # the CT-ViT plane: 4 strips of 6 per row, 384 threads
     (3, 1, 4, 7, 16),        # single time step, ragged strip (7 = 6 + 1)
+    (3, 24, 24, 24, 64),     # the CT-ViT grid: 24 planes of 24 x 24, several batch items per workgroup chunk
     (1, 2, 3, 5, 48),        # T = 2: the backward drain stores both remaining planes
     (2, 4, 9, 13, 16),       # odd plane
     (1, 3, 30, 30, 16),      # plane too large for one workgroup -> generic sweep kernel
@@ -1158,6 +1159,22 @@ def test_peg_kernels(hip, B, T, H, W, d, residual):
     hip.peg_bwd_weight(dy, x, dw27, db, B, T, H, W, d)
     check("peg dw", dw27.t().reshape(d, 1, 3, 3, 3), wr.grad, 1e-4)
     check("peg db", db, br.grad, 1e-4)
+    # both gradients in ONE pass over dy (ctclip_peg_bwd_fused): the same results, for the grids its plane tiling takes
+    from ctclip_hip import ops
+    dx2, dx2_16 = torch.full_like(x, 7.0), torch.empty(x.shape, device=DEV, dtype=torch.bfloat16)
+    dw2, db2 = torch.zeros(27, d, device=DEV), torch.zeros(d, device=DEV)
+    if ops.peg_fused_ok(H, W, d):
+        hip.peg_bwd_fused(dy, x, w27, dx2, dx2_16, dw2, db2, B, T, H, W, d, residual)
+        check("fused peg dx", dx2, xr.grad, 1e-5)
+        check("fused peg dx16", dx2_16, xr.grad, 1e-2)
+        check("fused peg dw", dw2.t().reshape(d, 1, 3, 3, 3), wr.grad, 1e-4)
+        check("fused peg db", db2, br.grad, 1e-4)
+        dw3, db3 = torch.zeros_like(dw2), torch.zeros_like(db2)
+        hip.peg_bwd_fused(dy, x, w27, dx2, None, dw3, db3, B, T, H, W, d, residual)
+        assert torch.equal(dw3, dw2) and torch.equal(db3, db2)                 # two-stage sums: bit-reproducible
+    else:
+        with pytest.raises(RuntimeError):
+            hip.peg_bwd_fused(dy, x, w27, dx2, dx2_16, dw2, db2, B, T, H, W, d, residual)
 
 
 # ---------------------------------------------------------------------------------------------- elementwise

@@ -39,3 +39,4 @@ if STAMPS: show_stamps("fwd")
 t = timeit(lambda: hip.peg_bwd_data(dy, w27, y, y16, B, T, H, W, d, 1)); print(f"peg_bwd_data   {t:9.1f} us  {(2.5 * gb) / t * 1e6 / 1e3:6.2f} TB/s")
 if STAMPS: show_stamps("bwd")
 t = timeit(lambda: hip.peg_bwd_weight(dy, x, dw, db, B, T, H, W, d)); print(f"peg_bwd_weight {t:9.1f} us  {(2.0 * gb) / t * 1e6 / 1e3:6.2f} TB/s (x + dy read)")
+t = timeit(lambda: hip.peg_bwd_fused(dy, x, w27, y, y16, dw, db, B, T, H, W, d, 1)); print(f"peg_bwd_fused  {t:9.1f} us  {(3.5 * gb) / t * 1e6 / 1e3:6.2f} TB/s (x + dy read, dx f32 + bf16 written: data and weight gradient in one pass)")
