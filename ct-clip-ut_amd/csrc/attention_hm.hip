@@ -33,6 +33,9 @@
 // wave with 16 or 12 waves (K / V fetched twice as often: 1437 / 1412 us), touching the wave's next sequence in L2 one
 // sequence ahead (1137 us: the first touch is not what the tiles wait for).
 #include "attn_common.h"
+#ifndef HM_ABL_HOT
+#define HM_ABL_HOT 0                  // diagnostic build, timing only: the backward's streamed operand is always L2-hot (profiles/r05_attention_bwd_fetch_ablation.txt)
+#endif
 #ifndef HM_STAMPS
 #define HM_STAMPS 0                   // diagnostic build: per-wave cycle totals of the forward's phases (tools/bench_attn_hm.py STAMPS=1)
 #endif
@@ -419,8 +422,13 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dq_kernel(HmArgs a) {
 
   for (int seq = hm_next_seq(&seq_counter, lane); seq < seq1; seq = hm_next_seq(&seq_counter, lane)) {
     const long base = ((long)seq * a.heads + head) * hstride;
-    const bf16_t* kb = a.k + base + kvoff;
-    const bf16_t* vb = a.v + base + kvoff;
+#if HM_ABL_HOT        // timing-only ablation (results wrong): the streamed K/V tiles always come from the chunk's first sequence
+    const long sbase = ((long)seq0 * a.heads + head) * hstride;
+#else
+    const long sbase = base;
+#endif
+    const bf16_t* kb = a.k + sbase + kvoff;
+    const bf16_t* vb = a.v + sbase + kvoff;
     bf16x8 kr[2][2], vr[2][2];
     auto request = [&](int slot, int t) {
       kr[slot][0] = as_bf16x8(*(const short8v*)(kb + (uint32_t)t * 1024));
@@ -633,8 +641,13 @@ __global__ __launch_bounds__(NW * 64, 1) void hm_bwd_dkv_kernel(HmArgs a) {
 
   for (int seq = hm_next_seq(&seq_counter, lane); seq < seq1; seq = hm_next_seq(&seq_counter, lane)) {
     const long base = ((long)seq * a.heads + head) * hstride;
-    const bf16_t* qb = a.q + base + qoff;
-    const bf16_t* dob = a.dO + base + qoff;
+#if HM_ABL_HOT        // timing-only ablation (results wrong): the streamed Q/dO tiles always come from the chunk's first sequence
+    const long sbase = ((long)seq0 * a.heads + head) * hstride;
+#else
+    const long sbase = base;
+#endif
+    const bf16_t* qb = a.q + sbase + qoff;
+    const bf16_t* dob = a.dO + sbase + qoff;
     bf16x8 qr[2][2], gr[2][2];
     auto request = [&](int slot, int t) {
       qr[slot][0] = as_bf16x8(*(const short8v*)(qb + (uint32_t)t * 1024));
