@@ -90,11 +90,12 @@ def test_gemm_pipelined_variant(hip, akm, bkm, M, N, K, split):
 @pytest.mark.parametrize("M,N,K,split", [(512, 768, 4096, 5),     # interior tiles, uneven last split
                                          (2816, 512, 2048, 3),    # FF1 weight-gradient shape (11 x 2 tiles)
                                          (520, 1408, 1024, 4),    # ragged in both directions (FF2: 5.5 tiles)
+                                         (304, 200, 32 * 23, 2),  # splits of 12 and 11 K-steps
                                          (256, 264, 96, 2),       # fewer K-steps (3) than ring stages
                                          (72, 40, 32, 1)])        # one K-step, one partial tile
 def test_gemm_weight_gradient_kernel(hip, M, N, K, split):
     """dW += alpha dy^T x with both operands row-major over the tokens (torch.nn.Linear backward): the 256x256x32
-    transposed-operand kernel (csrc/gemm4.hip) with split-K atomics into a running sum."""
+    transposed-operand kernel (csrc/gemm4.hip) with split-K through the workspace / atomics into a running sum."""
     A, B = bf(rnd(K, M, seed=1)), bf(rnd(K, N, seed=2))
     ref = A.float().t() @ B.float()
     run = rnd(M, N, seed=6)

@@ -291,11 +291,14 @@ def test_no_read_of_registers_an_asm_load_has_in_flight(tmp_path):
     import sys
     if shutil.which("hipcc") is None:
         pytest.skip("no hipcc")
-    src = os.path.join(ROOT, "ct-clip-ut_amd", "csrc", "patch_gemm.hip")
-    out = str(tmp_path / "patch_gemm.s")
-    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-std=c++17", "-Wno-unused-value",
-                        "--cuda-device-only", "-S", "-o", out, src], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    for kernel in ("patch_gemm_fwd_kernel", "patch_wgrad_kernel"):
-        c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight.py"), out, kernel], capture_output=True, text=True)
-        assert c.returncode == 0, c.stdout[-2000:]
+    # the same holds for the inline-asm transposed LDS reads (ds_read_b64_tr_b16) of the weight-gradient kernels: on no path to the
+    # tied s_waitcnt lgkmcnt(0) may their destination be read or re-used (round 5: a one-wave-per-SIMD variant faulted on a dead one)
+    for name, kernels in (("patch_gemm", ("patch_gemm_fwd_kernel", "patch_wgrad_kernel")), ("gemm4", ("gemm4_kernel",))):
+        src = os.path.join(ROOT, "ct-clip-ut_amd", "csrc", name + ".hip")
+        out = str(tmp_path / (name + ".s"))
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-munsafe-fp-atomics", "-std=c++17", "-Wno-unused-value",
+                            "--cuda-device-only", "-S", "-o", out, src], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for kernel in kernels:
+            c = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_inflight.py"), out, kernel], capture_output=True, text=True)
+            assert c.returncode == 0, c.stdout[-2000:]

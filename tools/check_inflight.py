@@ -48,6 +48,42 @@ def main(path, name):
                 dest = dest - regs(ops[0])                     # overwritten by something else: no longer the load's
                 if not dest:
                     break
+    # transposed LDS reads (ds_read_b64_tr_b16 is always inline asm here): on every path from the read to the next s_waitcnt
+    # lgkmcnt(0) nobody may read OR write the destination -- a write (the compiler reusing the register of a result it believes
+    # dead) is clobbered when the read lands.  Paths follow the branches (the loops are rotated: the wait often sits at a label).
+    full = [l.split(";")[0].strip() for l in lines[start:end]]
+    full = [l for l in full if l and not (l.startswith(".") and not l.endswith(":"))]
+    label_at = {l[:-1]: i for i, l in enumerate(full) if l.endswith(":")}
+    for i, l in enumerate(full):
+        m = re.match(r"ds_read_b64_tr_b16\s+(\S+?),", l)
+        if not m:
+            continue
+        dest = regs(m.group(1))
+        seen, todo, hit = set(), [i + 1], None
+        while todo and hit is None:
+            j = todo.pop()
+            while j < len(full) and j not in seen:
+                seen.add(j)
+                x = full[j]
+                if x.endswith(":"):
+                    j += 1
+                    continue
+                if re.match(r"s_waitcnt.*lgkmcnt\(0\)", x):
+                    break
+                ops = re.findall(r"v\[\d+:\d+\]|v\d+", x)
+                if any(regs(o) & dest for o in ops):
+                    hit = x
+                    break
+                br = re.match(r"(s_branch|s_cbranch_\w+)\s+(\S+)", x)
+                if br:
+                    if br.group(2) in label_at:
+                        todo.append(label_at[br.group(2)])
+                    if br.group(1) == "s_branch":
+                        break
+                j += 1
+        if hit:
+            print(f"  in-flight {m.group(1)} (ds_read_b64_tr_b16 at +{i}) touched by: {hit}")
+            bad += 1
     print(f"{name}: {bad} read(s) of in-flight registers")
     return 1 if bad else 0
 
