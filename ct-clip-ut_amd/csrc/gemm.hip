@@ -447,13 +447,15 @@ extern "C" int ctclip_geglu_bwd(const void* dg, const void* h, void* dh, long ro
                                 void* stream);
 
 namespace {
-// gemm5.hip (one wave per SIMD, 128 x 128 per wave, paired full-line LDS-DMA) takes the k-major x k-major products on which it
-// measured faster than gemm3.hip's 8 x (128 x 64) tile (profiles/r04_gemm5.txt, interleaved on one box, 32 pairs): FF1 + GEGLU
-// (1831 vs 1931 us) and plain products with many column tiles (N >= 2048: FF1 forward 885 vs 830 TFLOP/s); gemm3 stays on
-// the N <= 1408 shapes (kv forward 765 vs 788, out-projection 508 vs 534) and on FF2 dgrad + GEGLU backward (1548 vs 1462 us).
-// K % 64 == 0 and K >= 192 (six K-steps: the ring fill).  Under the test hook CTCLIP_GEMM_V2_ALL every eligible product with
-// K >= 1024 goes to gemm5 IN ADDITION to the shapes a training run sends there, so that the suite reaches all of its epilogues
-// with small shapes (the other products with K < 1024 keep exercising gemm3); ctclip_gemm5_bf16 calls the kernel directly.
+// gemm5.hip (one wave per SIMD, 128 x 128 per wave, paired full-line LDS-DMA, one request per 8 MFMAs) takes the k-major x k-major
+// products on which it measured faster than gemm3.hip's 8 x (128 x 64) tile, interleaved on one box at 32 pairs: FF1 + GEGLU (1831 vs
+// 1931 us) and plain products with many column tiles (N >= 2048: FF1 forward 885 vs 830 TFLOP/s) -- profiles/r04_gemm5.txt -- and,
+// since its requests are evenly spaced (round 5, profiles/r05_gemm5_even_issue.txt), every plain product with a long matrix loop
+// (K >= 1024: FF1 data gradient 1133 vs 1058 TFLOP/s, FF2 forward 817 vs 783); gemm3 stays on the short-K N <= 1408 shapes (kv forward
+// 765 vs 788, out-projection 508 vs 534) and on FF2 dgrad + GEGLU backward (1548 vs 1462 us).
+// K % 64 == 0 and K >= 192 (six K-steps: the ring fill).  Under the test hook CTCLIP_GEMM_V2_ALL the GEGLU-backward form with
+// K >= 1024 goes to gemm5 as well, so that the suite reaches all of its epilogues with small shapes (products with K < 1024 keep
+// exercising gemm3); ctclip_gemm5_bf16 calls the kernel directly.
 // CTCLIP_GEMM5_MINK (-DCTCLIP_TUNING_KNOBS builds: A/B runs) makes K >= that value the only criterion.
 bool gemm5_takes(int N, int K, int act) {
   static const bool v2_all = getenv("CTCLIP_GEMM_V2_ALL") != nullptr;
@@ -461,7 +463,7 @@ bool gemm5_takes(int N, int K, int act) {
   if ((K % 64) != 0 || K < 192) return false;
   if (mink >= 0) return K >= mink;
   if (v2_all && K >= 1024) return true;
-  return act == 2 || (act <= 1 && N >= 2048);
+  return act == 2 || (act <= 1 && (N >= 2048 || K >= 1024));
 }
 // every k-major x k-major launch of the 256 x 256 LDS-DMA kernels goes through here: gemm5 when it takes the shape and the
 // output allows the 16-byte register epilogue (asked BEFORE launching: an error of the launch itself is reported, not retried

@@ -11,8 +11,8 @@
 //     fragments are double-buffered (96 registers): the 16 ds_read_b128 of K-step j + 1 go out between the 64 MFMAs of K-step j
 //     (one wave can hide them under its own MFMAs), ONE barrier per K-step;
 //   * the same k32 LDS tiles, source-side swizzle and permuted N-fragment rows as gemm3.hip (gemm_tile.h), five slots of 32 KiB
-//     (all 160 KiB of LDS) filled by global_load_lds with counted vmcnt, PAIRED: both k32 halves of a 128-byte operand line
-//     are requested back to back so that the L1 sends one request per line (see the kernel);
+//     (all 160 KiB of LDS) filled by global_load_lds with counted vmcnt, PAIRED (both k32 halves of a 128-byte operand line are
+//     requested close together so that the L1 sends one request per line) and EVENLY SPACED: one request per 8 MFMAs (see the kernel);
 //   * the (tile, K-step) sequence of a workgroup is FLATTENED: the ring never drains between tiles, the loop body is
 //     branch-free and every wait count is a constant;
 //   * the register epilogue of gemm_tile.h, once per 64-column slab of the wave's 128 columns.
@@ -69,13 +69,15 @@ __global__ __launch_bounds__(256) void gemm5_kernel(Args g) {
   constexpr int PPW = STAGE / 1024 / 4;              // 1 KiB DMA pieces per wave and slot: 8
   constexpr int NST = 2 * IM * (EPI == 0 ? 2 : EPI == 2 ? 3 : 4);   // 16-byte stores per wave of a full tile's register epilogue
   static_assert(NS == 5, "the paired issue below is written for five slots");
-  // PAIRED ISSUE: the two k32 halves of the same 128-byte operand lines are requested back to back -- K-steps 2P + 4 and 2P + 5
-  // during step 2P, nothing during the odd steps -- so the second request merges with the first in the L1 and the L1 -> L2 request
-  // count is that of full lines (measured: profiles/r04_gemm5.txt sections 6, 7; one K-step's pieces per step with four slots
-  // was 5-9 % slower).  The two K-steps of a pair are issued piece by piece INTERLEAVED, so a K-step is only known complete
-  // when its whole pair is: when K-step j + 2 must have landed, what may stay in flight is the one pair issued after its pair.
-  constexpr int C_DMA = 2 * PPW;
-  constexpr int C_ST = C_DMA + NST > 63 ? 63 : C_DMA + NST;   // ... and an epilogue's stores behind it (vmcnt holds 6 bits)
+  // PAIRED, EVENLY SPACED ISSUE: the two k32 halves of the same 128-byte operand lines go to two ring slots (K-steps 2P + 4 and
+  // 2P + 5); the second request for a line merges with the first in the L1, so the L1 -> L2 request count is that of full lines
+  // (profiles/r04_gemm5.txt sections 6, 7).  Round 5: ONE request per row group of 8 MFMAs -- pieces 0-3 of the pair (both halves,
+  // alternating) during step 2P, pieces 4-7 during step 2P + 1 -- instead of all sixteen during the even step and none during
+  // the odd one: the evenly spaced stream queues less in the memory system (FF1 data gradient 1004 -> 1071 TFLOP/s, FF2 forward
+  // 898 -> 932, five interleaved repetitions on one box: profiles/r05_gemm5_even_issue.txt; it is also what the vendor's kernel does,
+  // r05_vendor_isa.txt).  A K-step is only known complete when its whole pair is: K-step j + 2 and its partner were requested one
+  // and two steps before step j's own requests, so an even step may leave its PPW requests in flight, an odd step its own and the
+  // even step's.
   constexpr int NPRO = 4;                            // K-steps of the ring fill: two pairs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -129,6 +131,12 @@ __global__ __launch_bounds__(256) void gemm5_kernel(Args g) {
     G3_GLDS(ibase + v, lds0 + (uint32_t)(islot * STAGE) + dst0 + i * 1024);
     G3_GLDS(ibase + (v + half1), lds0 + (uint32_t)(s1 * STAGE) + dst0 + i * 1024);
   };
+  auto issue_half = [&](int i, int h) {               // one half of piece i: the main loop's single request per row group
+    const uint32_t v = min(voff0 + (uint32_t)i * rowstep, vlast);
+    const int s1 = islot + 1 == NS ? 0 : islot + 1;
+    if (h == 0) G3_GLDS(ibase + v, lds0 + (uint32_t)(islot * STAGE) + dst0 + i * 1024);
+    else G3_GLDS(ibase + (v + half1), lds0 + (uint32_t)(s1 * STAGE) + dst0 + i * 1024);
+  };
   locate_issue(itile);
 #pragma unroll
   for (int t = 0; t < NPRO; t += 2) {
@@ -179,14 +187,16 @@ __global__ __launch_bounds__(256) void gemm5_kernel(Args g) {
       fa[i] = *(const bf16x8*)(st + offA + i * 1024);
       if (i < IM - 1) fbn[i] = *(const bf16x8*)(st + offB(i));
       if (i == IM - 2) fbn[JN - 1] = *(const bf16x8*)(st + offB(JN - 1));
-      if constexpr (!ODD) issue_piece(i);
+      issue_half((ODD ? PPW / 2 : 0) + (i >> 1), i & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (!ODD) advance_issue();
+    if constexpr (ODD) advance_issue();
     cslot = nslot;
     G5_SEG(0); G5_CNT(5);
     // own pieces of the K-step after the next landed (it is read during the next step, behind this barrier)
-    if (post > 0) { wait_vm<C_ST>(); --post; } else wait_vm<C_DMA>();
+    // (an epilogue's NST stores may stay in flight behind them for the two steps after it; vmcnt holds 6 bits)
+    constexpr int C_SP = ODD ? 2 * PPW : PPW, C_SPST = C_SP + NST > 63 ? 63 : C_SP + NST;
+    if (post > 0) { wait_vm<C_SPST>(); --post; } else wait_vm<C_SP>();
     G5_SEG(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads of slot `nslot` retired before the barrier that frees it
     G5_SEG(2);

@@ -387,8 +387,9 @@ __global__ __launch_bounds__(WG_MAXT * WG_C2 / 8, 3) void peg_wgrad_plane_kernel
   const int slice = blk % nslices;
   const long b0 = (long)(blk / nslices) * bchunk, b1 = (b0 + bchunk < g.B) ? b0 + bchunk : g.B;
   const int c2 = tid & (WG_C2 - 1), sid = tid / WG_C2;
-  const int h_ = sid / strips, strip = sid % strips, w0 = strip * PL_P;
-  const bool active = h_ < g.H;
+  const int h_raw = sid / strips, strip = sid % strips, w0 = strip * PL_P;
+  const bool active = h_raw < g.H;
+  const int h_ = active ? h_raw : 0;                         // idle threads read row 0's neighbours (see peg_bwd_fused_kernel)
   const int pitch = plane_pitch(strips);
   const int plane_f2 = (g.H + 2) * pitch * WG_C2;
   f32x2* ring = wg_smem;                                     // [3][(H+2)][pitch][WG_C2]
@@ -542,8 +543,12 @@ __global__ __launch_bounds__(FUSED_MAXT, 2) void peg_bwd_fused_kernel(const floa
   const int slice = blk % nslices;
   const long b0 = (long)(blk / nslices) * bchunk, b1 = (b0 + bchunk < g.B) ? b0 + bchunk : g.B;
   const int c2 = tid & (WG_C2 - 1), sid = tid / WG_C2;
-  const int h_ = sid / strips, strip = sid % strips, w0 = strip * FP;
-  const bool active = h_ < g.H;
+  const int h_raw = sid / strips, strip = sid % strips, w0 = strip * FP;
+  const bool active = h_raw < g.H;
+  // threads past the last row (the block is rounded up to whole waves) still run the neighbour reads: on row 0, inside the
+  // initialised ring -- their own x is zero, and 0 x (whatever a stray LDS word holds, possibly a NaN pattern) must not reach the
+  // weight-gradient sums they share with the active lanes
+  const int h_ = active ? h_raw : 0;
   const int pitch = fused_pitch(strips);
   const int plane_f2 = (g.H + 2) * pitch * WG_C2;
   f32x2* ring = wg_smem;                                     // [3][(H+2)][pitch][WG_C2]: dy planes t, t+1, t+2

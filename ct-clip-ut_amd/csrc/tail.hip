@@ -436,3 +436,24 @@ extern "C" int ctclip_probe_mfma(float* out, int blocks, int iters, void* stream
   hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, iters);
   CTCLIP_CHECK_LAUNCH();
 }
+
+// diagnostic / test hook: fill the whole LDS of every CU with a 32-bit pattern (LDS is not cleared between kernels: a kernel that
+// reads a word it never wrote sees what the previous tenant left -- with two processes on one device, anything).  Tests poison the
+// LDS with a NaN pattern in front of kernels that round their blocks up to whole waves (tests/test_hip_kernels.py).
+namespace {
+__global__ __launch_bounds__(1024) void lds_fill_kernel(uint32_t pattern, int words, uint32_t* sink) {
+  extern __shared__ uint32_t lds_fill_smem[];
+  for (int i = threadIdx.x; i < words; i += blockDim.x) lds_fill_smem[i] = pattern;
+  __syncthreads();
+  if (sink && lds_fill_smem[(threadIdx.x * 97) % words] != pattern) sink[0] = 1;    // keeps the stores alive
+}
+}  // namespace
+extern "C" int ctclip_probe_lds_fill(int pattern, void* sink, void* stream) {
+  constexpr int bytes = 160 * 1024;
+  CTCLIP_LDS_LIMIT_ONCE(lds_fill_kernel, bytes);
+  // one 160 KiB workgroup per CU at a time; several rounds so that every CU is visited whatever else is resident
+  hipLaunchKernelGGL(lds_fill_kernel, dim3(ctclip_cu_count8() * 4), dim3(1024), bytes, (hipStream_t)stream, (uint32_t)pattern,
+                     bytes / 4, (uint32_t*)sink);
+  CTCLIP_CHECK_LAUNCH();
+}
+

@@ -138,7 +138,17 @@ class _Hip:
         has_partials = has_stream and nargs >= 2 and proto[-2][1] == "partials"
         has_splitk = has_stream and nargs >= 3 and proto[-3][1] == "splitk_ws" and proto[-2][1] == "splitk_ws_floats"
 
+        # test hook CTCLIP_TEST_POISON_LDS=1: every launch is preceded by ctclip_probe_lds_fill with a NaN pattern -- LDS is not
+        # cleared between kernels, so a kernel that reads a word it never wrote (idle threads of a block rounded up to whole waves,
+        # halo columns) otherwise sees whatever the previous tenant left, which is benign until another process shares the device
+        poison = has_stream and os.environ.get("CTCLIP_TEST_POISON_LDS") and full != "ctclip_probe_lds_fill"
+
         def call(*args):
+            if poison:
+                dev = torch.cuda.current_device()
+                if dev not in _poison_sink:
+                    _poison_sink[dev] = torch.zeros(4, dtype=torch.int32, device=f"cuda:{dev}")
+                self.probe_lds_fill(0x7FC00000, _poison_sink[dev])
             if has_partials and len(args) == nargs - 2:
                 args = (*args, partials_scratch())
             if has_splitk and len(args) == nargs - 3:
@@ -180,4 +190,5 @@ class _Hip:
         return call
 
 
+_poison_sink = {}
 hip = _Hip()

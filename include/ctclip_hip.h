@@ -421,6 +421,11 @@ int ctclip_probe_mfma(float* out, int blocks, int iters, void* stream);
 int ctclip_probe_copy(const void* src, void* dst, long bytes, void* stream);
 int ctclip_probe_stream(const void* src, void* dst, long bytes, int mode, void* stream);
 
+/* ---- diagnostic / test hook: fill the whole LDS (160 KiB) of every CU with a 32-bit pattern; `sink`: 4 bytes of device scratch.
+ * LDS is not cleared between kernels, so a kernel that reads a word it never wrote sees the previous tenant's data; tests poison the
+ * LDS with a NaN pattern in front of the kernels whose blocks are rounded up to whole waves (no reference counterpart) ---- */
+int ctclip_probe_lds_fill(int pattern, void* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1124,7 +1124,8 @@ def test_patch_affine_fold_and_backward(hip, N, F_, M):
 # ---------------------------------------------------------------------------------------------- PEG
 @pytest.mark.parametrize("B,T,H,W,d", [
     (2, 5, 24, 24, 32),      # the CT-ViT plane: 4 strips of 6 per row, 384 threads
-    (3, 1, 4, 7, 16),        # single time step, ragged strip (7 = 6 + 1)
+    (3, 1, 4, 7, 16),        # single time step, ragged strip (7 = 6 + 1); half of the block's one wave is idle
+    (2, 4, 4, 4, 512),       # the 64^3 debug volume's grid: 32 of 64 threads idle in every workgroup
     (3, 24, 24, 24, 64),     # the CT-ViT grid: 24 planes of 24 x 24, several batch items per workgroup chunk
     (1, 2, 3, 5, 48),        # T = 2: the backward drain stores both remaining planes
     (2, 4, 9, 13, 16),       # odd plane
@@ -1157,6 +1158,11 @@ def test_peg_kernels(hip, B, T, H, W, d, residual):
     check("peg dx16", dx16, xr.grad, 1e-2)
     dw27 = torch.zeros(27, d, device=DEV)
     db = torch.zeros(d, device=DEV)
+    # LDS is not cleared between kernels: the weight-gradient kernels round their blocks up to whole waves, and an idle thread's
+    # zero x times whatever a stray LDS word holds must not reach the sums (round 5: two processes on one device left NaN patterns
+    # there and the step's loss went NaN for grids whose rows x strips x 8 is no multiple of 64) -- poison the LDS first
+    sink = torch.zeros(4, device=DEV, dtype=torch.int32)
+    hip.probe_lds_fill(0x7FC00000, sink)
     hip.peg_bwd_weight(dy, x, dw27, db, B, T, H, W, d)
     check("peg dw", dw27.t().reshape(d, 1, 3, 3, 3), wr.grad, 1e-4)
     check("peg db", db, br.grad, 1e-4)
@@ -1165,6 +1171,7 @@ def test_peg_kernels(hip, B, T, H, W, d, residual):
     dx2, dx2_16 = torch.full_like(x, 7.0), torch.empty(x.shape, device=DEV, dtype=torch.bfloat16)
     dw2, db2 = torch.zeros(27, d, device=DEV), torch.zeros(d, device=DEV)
     if ops.peg_fused_ok(H, W, d):
+        hip.probe_lds_fill(0x7FC00000, sink)
         hip.peg_bwd_fused(dy, x, w27, dx2, dx2_16, dw2, db2, B, T, H, W, d, residual)
         check("fused peg dx", dx2, xr.grad, 1e-5)
         check("fused peg dx16", dx2_16, xr.grad, 1e-2)

@@ -18,6 +18,7 @@ shapes = [  # name, M, N, K, akm, bkm, c_fp32, split, accumulate   (I = 1365, pa
     ("patch fwd f32", T, 512, 4000, 1, 1, 1, 1, 0),
     ("ff2 dgrad", T, 1408, 512, 1, 1, 0, 1, 0),
     ("ff1 dgrad f32", T, 512, 2816, 1, 1, 1, 1, 0),
+    ("ff1 dgrad bf16", T, 512, 2816, 1, 1, 0, 1, 0),
     ("out dgrad", T, 256, 512, 1, 1, 0, 1, 0),
     ("q dgrad f32", T, 512, 256, 1, 1, 1, 1, 0),
     ("kv dgrad f32", T, 512, 512, 1, 1, 1, 1, 0),

@@ -5,11 +5,15 @@ sys.path.insert(0, os.path.join(ROOT, "ct-clip-ut_amd"))
 import torch
 from ctclip_hip.lib import hip
 B = int(os.environ.get("B", 32))
+REP = int(os.environ.get("REP", 5))
+ONLY = os.environ.get("ONLY")
 T = 13824 * B
 dev = "cuda"
 shapes = [("sq4096", 4096, 4096, 4096, 0, 0), ("ff1 fwd", T, 2816, 512, 0, 0), ("ff1 + geglu", T, 2816, 512, 0, 2),
           ("ff2 fwd f32", T, 512, 1408, 1, 0), ("ff1 dgrad f32", T, 512, 2816, 1, 0), ("kv fwd", T, 512, 512, 0, 0)]
 for name, M, N, K, cf, act in shapes:
+    if ONLY and not any(o in name for o in ONLY.split(",")):
+        continue
     A = torch.randn(M, K, device=dev).to(torch.bfloat16)
     Bm = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
     C = torch.empty(M, N, device=dev, dtype=torch.float32 if cf else torch.bfloat16)
@@ -19,10 +23,10 @@ for name, M, N, K, cf, act in shapes:
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5):
+    for _ in range(REP):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / 5 * 1e3
+    t = e0.elapsed_time(e1) / REP * 1e3
     print(f"{name:16s} M={M:8d} N={N:5d} K={K:5d}  {t:9.1f} us  {2.0 * M * N * K / t / 1e6:8.1f} TFLOP/s")
     del A, Bm, C, G
