@@ -202,7 +202,10 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
     const bool upper = ml >= 8;
     const int rsub = ml & 7, hsel = ml >> 3;
         if constexpr (F32OUT) {
-      float4 rs[2][4];
+      // ring of row groups whose reads are in flight: three ahead of the one being worked on (round 5: 819 -> 805 us on FF2 + residual at
+      // 32 pairs against one ahead; profiles/r05_epilogue_read_ahead.txt)
+      constexpr int RD = AHEAD ? 4 : 1;
+      float4 rs[RD][4];
       auto ld_resid = [&](int i, float4 (&dst)[4]) {
         const int row = rbase + i * 16 + ml;
 #pragma unroll
@@ -211,12 +214,16 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
           dst[j] = (g.resid && row < g.M && col < g.N) ? *(const float4*)(g.resid + (long)row * g.ldr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       };
-      if (AHEAD) ld_resid(0, rs[0]);
+      if (AHEAD) {
+#pragma unroll
+        for (int d = 0; d < RD - 1; ++d)
+          if (d < IM) ld_resid(d, rs[d]);
+      }
 #pragma unroll
       for (int i = 0; i < IM; ++i) {
         __builtin_amdgcn_sched_barrier(0);         // one row group at a time
-        if (AHEAD) { if (i + 1 < IM) ld_resid(i + 1, rs[(i + 1) & 1]); }
-        else ld_resid(i, rs[i & 1]);
+        if (AHEAD) { if (i + RD - 1 < IM) ld_resid(i + RD - 1, rs[(i + RD - 1) % RD]); }
+        else ld_resid(i, rs[0]);
         uint4 pk[4];
         float k1 = 0.f, k2 = 0.f;                    // EPI 4: this lane's row constants
         if constexpr (LNB) {
@@ -237,7 +244,7 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
             x[2] -= fmaf(__uint_as_float(xw.y << 16), k2, k1);
             x[3] -= fmaf(__uint_as_float(xw.y & 0xffff0000u), k2, k1);
           }
-          const float4 r = rs[i & 1][j];
+          const float4 r = rs[i % RD][j];
           x[0] += r.x; x[1] += r.y; x[2] += r.z; x[3] += r.w;
           if (act == 1) { x[0] = gelu_erf(x[0]); x[1] = gelu_erf(x[1]); x[2] = gelu_erf(x[2]); x[3] = gelu_erf(x[3]); }
           pk[j] = f4_bits(x[0], x[1], x[2], x[3]);
@@ -291,7 +298,8 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
       // dg = dy W2 with the GEGLU backward: this tile's dg never goes to memory; the matching value / gate
       // pre-activations are read from h and replaced by their gradients in place.  Column c of dg: its value sits at
       // (c / 32) * 64 + c % 32 of h, the gate 32 further -- value and gate pieces of a lane are the two halves of one line
-      uint4 hv[2][4];                                // [buffer][2 h + {value, gate}]
+      constexpr int RD = AHEAD ? 3 : 1;              // two row groups of h in flight ahead (1472 -> 1455 us at 32 pairs against one)
+      uint4 hv[RD][4];                               // [buffer][2 h + {value, gate}]
       auto ld_h = [&](int i, uint4 (&dst)[4]) {
         const int row = rbase + i * 16 + ml;
 #pragma unroll
@@ -303,17 +311,21 @@ __device__ __forceinline__ void epilogue_slab(const Args& g, f32x4 (&acc)[IM][NJ
           dst[2 * h + 1] = ok ? *(const uint4*)(hp + 32) : make_uint4(0u, 0u, 0u, 0u);
         }
       };
-      if (AHEAD) ld_h(0, hv[0]);
+      if (AHEAD) {
+#pragma unroll
+        for (int d = 0; d < RD - 1; ++d)
+          if (d < IM) ld_h(d, hv[d]);
+      }
 #pragma unroll
       for (int i = 0; i < IM; ++i) {
         __builtin_amdgcn_sched_barrier(0);
-        if (AHEAD) { if (i + 1 < IM) ld_h(i + 1, hv[(i + 1) & 1]); }
-        else ld_h(i, hv[i & 1]);
+        if (AHEAD) { if (i + RD - 1 < IM) ld_h(i + RD - 1, hv[(i + RD - 1) % RD]); }
+        else ld_h(i, hv[0]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           float val[8], gate[8], dv[8], dt[8];
-          unpack8(hv[i & 1][2 * h], val);
-          unpack8(hv[i & 1][2 * h + 1], gate);
+          unpack8(hv[i % RD][2 * h], val);
+          unpack8(hv[i % RD][2 * h + 1], gate);
 #pragma unroll
           for (int e = 0; e < 8; e += 2) {             // pairs: packed-f32 arithmetic, one Phi for gelu and its derivative
             const f32x2 dgv = f32x2{acc[i][J0 + 2 * h + (e >> 2)][e & 3], acc[i][J0 + 2 * h + (e >> 2)][(e & 3) + 1]} * pk_splat(g.alpha);
