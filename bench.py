@@ -812,7 +812,7 @@ def main():
                        "parallelism": f"dp{world}", "peak_hbm_gib": round(peak_mem, 1), "final_loss": float(loss)},
             "roofline": {"kernel": "ctclip_gemm_bf16 family (gemm3_kernel: 8 waves x 128 x 64, the k-major products incl. FF2 dgrad + GEGLU', the "
                                    "head-major and LayerNorm-backward epilogues; gemm5_kernel: one wave per SIMD, 4 x 128 x 128, FF1 + GEGLU and "
-                                   "N >= 2048; gemm4_kernel: the gemm3 tile with transposed operands, weight gradients; gemm2 / gemm_bf16 "
+                                   "N >= 2048 and, evenly spaced requests, every plain K >= 1024 product; gemm4_kernel: the gemm3 tile with transposed operands, weight gradients; gemm2 / gemm_bf16 "
                                    "kernels for small grids)",
                          "bound": "mfma", "achieved": gemm_tflops,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tflops / PEAK_BF16_TFLOPS,
