@@ -22,6 +22,7 @@ shapes = [  # name, M, N, K, akm, bkm, c_fp32, split, accumulate   (I = 1365, pa
     ("out dgrad", T, 256, 512, 1, 1, 0, 1, 0),
     ("q dgrad f32", T, 512, 256, 1, 1, 1, 1, 0),
     ("kv dgrad f32", T, 512, 512, 1, 1, 1, 1, 0),
+    ("attn dgrad f32 k768", T, 512, 768, 1, 1, 1, 1, 0),
     ("ff1 wgrad", 2816, 512, T, 0, 0, 1, 0, 1),
     ("ff2 wgrad", 512, 1408, T, 0, 0, 1, 0, 1),
     ("out wgrad", 512, 256, T, 0, 0, 1, 0, 1),
