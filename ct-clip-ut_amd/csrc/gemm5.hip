@@ -1,6 +1,6 @@
 // bf16 MFMA GEMM, 256 x 256 tile, ONE WAVE PER SIMD: 4 waves x (128 x 128).  Takes the k-major x k-major products of the CT-CLIP
 // step on which it measured faster than gemm3.hip (dispatcher: csrc/gemm.hip, gemm5_takes): FF1 + GEGLU and plain products with
-// N >= 2048 (src/utils/attention.py:38-51; every nn.Linear of the path goes through ctclip_gemm_bf16).
+// N >= 2048 or K >= 1024 (src/utils/attention.py:38-51; every nn.Linear of the path goes through ctclip_gemm_bf16).
 //
 // Why a second tile shape.  gemm3.hip runs 8 waves x (128 x 64): per 32-deep K-step a wave reads 12 fragments for 32 MFMAs and
 // the two waves of a SIMD alternate between a load block and an MFMA block.  The vendor library's fastest kernels on the long-K

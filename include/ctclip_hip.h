@@ -65,7 +65,7 @@ int ctclip_gemm_bf16(const void* A, const void* B, void* C, const float* bias, c
 
 /* The same k-major x k-major product on the one-wave-per-SIMD kernel (csrc/gemm5.hip: 4 waves x 128 x 128, accumulators in
  * AccVGPRs, paired full-line LDS-DMA) CALLED DIRECTLY: ctclip_gemm_bf16 / _geglu / _geglu_bwd send it the shapes it measured
- * faster on (FF1 + GEGLU, N >= 2048); this entry takes any shape the kernel is eligible for -- K % 64 == 0, K >= 192, 16-byte
+ * faster on (FF1 + GEGLU, N >= 2048, plain products with K >= 1024); this entry takes any shape the kernel is eligible for -- K % 64 == 0, K >= 192, 16-byte
  * aligned outputs -- and returns hipErrorInvalidValue otherwise (so short rings, K = 192 .. 960, can be tested and measured
  * without a size gate).  act: 0 none, 1 erf-GELU, 2 = FF1 + GEGLU (C = h [M, N] in [value 32 | gate 32] blocks, G = g
  * [M, N / 2]), 3 = FF2 data gradient + GEGLU backward (G = h, overwritten by d(h); C unused).  Reference: every nn.Linear of
